@@ -1,0 +1,354 @@
+"""ORACLE (test infrastructure, not product code): CPU restatement of the reference's
+HunyuanVideo DiT denoise path in plain PyTorch fp32.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  It is pinned to the reference by tests/golden/dit_*.npz, which were produced by
+tools/make_golden.py importing /root/reference (hyvideo.modules.models) in the build
+container; tests/test_oracle_golden.py checks every function here against them.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference/hyvideo/).  State dicts use the reference's key names.
+
+`Prec` selects the numeric contract:
+  * Prec(False): everything fp32 (what the golden fixtures were generated with);
+  * Prec(True):  "bf16-emulated" - values stay fp32 tensors but are rounded to bf16 at the
+    points where production (torch.autocast("cuda", bf16) with bf16 parameters,
+    pipeline_hunyuan_video.py:988-990, inference.py:190) holds bf16: Linear/Conv inputs and
+    outputs, residual stream, (1+scale), gate products, RMSNorm before the gain, RoPE output,
+    softmax probabilities fed to P@V.  LayerNorm/RMSNorm/RoPE internals stay fp32
+    (SURVEY.md 8a).  This is what the GPU kernels are compared with at tight tolerance.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+class Prec:
+    def __init__(self, emulate_bf16: bool = False):
+        self.emu = emulate_bf16
+
+    def r(self, x: Tensor) -> Tensor:
+        """round to bf16 (and back to fp32) when emulating, identity otherwise"""
+        return x.to(torch.bfloat16).to(torch.float32) if self.emu else x
+
+    def linear(self, x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+        """nn.Linear under autocast: bf16 operands, fp32 accumulate + bias, one rounding."""
+        return self.r(F.linear(self.r(x), self.r(w), None if b is None else self.r(b)))
+
+
+FP32 = Prec(False)
+
+
+# ----------------------------------------------------------------------------- leaves
+def timestep_embedding(t: Tensor, dim: int = 256, max_period: float = 10000.0) -> Tensor:
+    """modules/embed_layers.py:93-117 - [cos(t*f) | sin(t*f)], f_i = exp(-ln(max_period)*i/half)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    args = t.reshape(-1, 1).float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def timestep_embedder(sd, prefix: str, t: Tensor, p: Prec) -> Tensor:
+    """modules/embed_layers.py:152-157 - sinusoid cast to weight dtype, Linear-SiLU-Linear."""
+    h = p.linear(timestep_embedding(t), sd[prefix + "mlp.0.weight"], sd[prefix + "mlp.0.bias"])
+    h = p.r(F.silu(h))
+    return p.linear(h, sd[prefix + "mlp.2.weight"], sd[prefix + "mlp.2.bias"])
+
+
+def rope_tables(sizes: Sequence[int], rope_dim_list: Sequence[int], theta: float = 256.0) -> Tuple[Tensor, Tensor]:
+    """modules/posemb_layers.py:191-310 (use_real=True) as called from inference.py:450-495.
+    Positions are the integer grid (t,h,w) in 'ij' order flattened t-major; per axis
+    freqs = 1/theta^(2i/dim); cos/sin repeat_interleave(2); axis blocks concatenated."""
+    grids = torch.meshgrid(*[torch.arange(n, dtype=torch.float32) for n in sizes], indexing="ij")
+    cos_l, sin_l = [], []
+    for dim, g in zip(rope_dim_list, grids):
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+        ang = torch.outer(g.reshape(-1), freqs)
+        cos_l.append(ang.cos().repeat_interleave(2, dim=1))
+        sin_l.append(ang.sin().repeat_interleave(2, dim=1))
+    return torch.cat(cos_l, dim=1), torch.cat(sin_l, dim=1)
+
+
+def apply_rope(x: Tensor, cos: Tensor, sin: Tensor, p: Prec) -> Tensor:
+    """modules/posemb_layers.py:133-137,165-171 - x:[B,S,H,D]; pairs (x0,x1)->(-x1,x0); fp32 math,
+    one rounding at the end (.type_as)."""
+    xf = x.float()
+    x0, x1 = xf.reshape(*xf.shape[:-1], -1, 2).unbind(-1)
+    rot = torch.stack([-x1, x0], dim=-1).flatten(3)
+    return p.r(xf * cos[None, :, None, :] + rot * sin[None, :, None, :])
+
+
+def rms_norm(x: Tensor, w: Tensor, p: Prec, eps: float = 1e-6) -> Tensor:
+    """modules/norm_layers.py:43,56-59 - normalise in fp32, cast to x's dtype, THEN multiply by the gain."""
+    xf = x.float()
+    y = p.r(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps))
+    return p.r(y * p.r(w))
+
+
+def ln_modulate(x: Tensor, shift: Optional[Tensor], scale: Optional[Tensor], p: Prec, eps: float = 1e-6) -> Tensor:
+    """nn.LayerNorm(no affine, eps 1e-6) (models.py:54-56,161) followed by modulate
+    (modulate_layers.py:31-49).  LN output is fp32 under CUDA autocast; (1+scale) is formed in
+    the dtype of scale (bf16) and promoted; the consumer Linear rounds the result (Prec.linear)."""
+    y = F.layer_norm(x.float(), (x.shape[-1],), None, None, eps)
+    if scale is not None:
+        y = y * p.r(1.0 + scale)[:, None, :]
+    if shift is not None:
+        y = y + shift[:, None, :]
+    return y
+
+
+def gate_residual(x: Tensor, y: Tensor, gate: Tensor, p: Prec) -> Tensor:
+    """x + apply_gate(y, gate) (modulate_layers.py:52-68; models.py:231,242,393): both the product and
+    the sum are rounded to the residual dtype."""
+    return p.r(x + p.r(y * gate[:, None, :]))
+
+
+def cu_seqlens(text_mask: Tensor, img_len: int) -> Tensor:
+    """modules/attenion.py:34-57 (without the hard-coded device): [0, img+n_valid, img+txt] per sample."""
+    b = text_mask.shape[0]
+    text_len = text_mask.sum(dim=1)
+    max_len = text_mask.shape[1] + img_len
+    cu = torch.zeros(2 * b + 1, dtype=torch.int32)
+    for i in range(b):
+        cu[2 * i + 1] = i * max_len + int(text_len[i]) + img_len
+        cu[2 * i + 2] = (i + 1) * max_len
+    return cu
+
+
+def sdpa(q: Tensor, k: Tensor, v: Tensor, p: Prec, mask: Optional[Tensor] = None) -> Tensor:
+    """softmax(q k^T / sqrt(D)) v for [B,S,H,D] inputs -> [B,S,H,D].  flash-attn 2.6.3 numerics in
+    emulated mode: fp32 scores/softmax statistics, probabilities rounded to bf16 for P@V, fp32
+    accumulate, normalise by the UNROUNDED row sum, round the output."""
+    qh, kh, vh = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
+    s = torch.matmul(qh, kh.transpose(-1, -2)) * (1.0 / math.sqrt(q.shape[-1]))
+    if mask is not None:
+        s = s.masked_fill(~mask, float("-inf"))
+    m = s.amax(dim=-1, keepdim=True)
+    e = torch.exp(s - m)
+    l = e.sum(dim=-1, keepdim=True)
+    o = torch.matmul(p.r(e), vh) / l
+    return p.r(o.permute(0, 2, 1, 3))
+
+
+def attention_varlen(q: Tensor, k: Tensor, v: Tensor, cu: Tensor, p: Prec) -> Tensor:
+    """modules/attenion.py:60-156 mode="flash": flash_attn_varlen_func semantics - tokens of the
+    flattened [(B*S),H,D] batch attend only inside their own [cu[i], cu[i+1]) segment (flash-attn is a
+    third-party dependency, v2.6.3, absent here: standard per-segment softmax attention).
+    Returns [B,S,H*D]."""
+    b, s, h, d = q.shape
+    qf, kf, vf = (t.reshape(1, b * s, h, d) for t in (q, k, v))
+    out = torch.zeros_like(qf, dtype=torch.float32)
+    for i in range(cu.numel() - 1):
+        lo, hi = int(cu[i]), int(cu[i + 1])
+        if hi > lo:
+            out[:, lo:hi] = sdpa(qf[:, lo:hi], kf[:, lo:hi], vf[:, lo:hi], p)
+    return out.reshape(b, s, h * d)
+
+
+def gelu_tanh(x: Tensor, p: Prec) -> Tensor:
+    """modules/activation_layers.py:16-18 - nn.GELU(approximate="tanh")."""
+    return p.r(F.gelu(x, approximate="tanh"))
+
+
+def modulation(sd, prefix: str, vec: Tensor, p: Prec) -> Tensor:
+    """modules/modulate_layers.py:7-28 - Linear(SiLU(vec))."""
+    return p.linear(p.r(F.silu(vec)), sd[prefix + "weight"], sd[prefix + "bias"])
+
+
+# ----------------------------------------------------------------------------- blocks
+def _split_heads(qkv: Tensor, heads: int):
+    """rearrange 'B L (K H D) -> K B L H D' (models.py:166-168)."""
+    b, l, _ = qkv.shape
+    return qkv.reshape(b, l, 3, heads, -1).unbind(2)
+
+
+def double_block(sd, pre: str, img: Tensor, txt: Tensor, vec: Tensor, cu: Tensor,
+                 cos: Optional[Tensor], sin: Optional[Tensor], heads: int, p: Prec,
+                 attn_fn=None) -> Tuple[Tensor, Tensor]:
+    """MMDoubleStreamBlock.forward, modules/models.py:132-252."""
+    attn_fn = attn_fn or attention_varlen
+    mods = {}
+    for s in ("img", "txt"):
+        mods[s] = modulation(sd, f"{pre}{s}_mod.linear.", vec, p).chunk(6, dim=-1)
+    qs, ks, vs = [], [], []
+    for s, x in (("img", img), ("txt", txt)):
+        sh1, sc1 = mods[s][0], mods[s][1]
+        xm = ln_modulate(x, sh1, sc1, p)
+        qkv = p.linear(xm, sd[f"{pre}{s}_attn_qkv.weight"], sd[f"{pre}{s}_attn_qkv.bias"])
+        q, k, v = _split_heads(qkv, heads)
+        q = rms_norm(q, sd[f"{pre}{s}_attn_q_norm.weight"], p)
+        k = rms_norm(k, sd[f"{pre}{s}_attn_k_norm.weight"], p)
+        if s == "img" and cos is not None:
+            q, k = apply_rope(q, cos, sin, p), apply_rope(k, cos, sin, p)
+        qs.append(q), ks.append(k), vs.append(v)
+    attn = attn_fn(torch.cat(qs, 1), torch.cat(ks, 1), torch.cat(vs, 1), cu, p)
+    n_img = img.shape[1]
+    outs = []
+    for s, x, a in (("img", img, attn[:, :n_img]), ("txt", txt, attn[:, n_img:])):
+        _, _, g1, sh2, sc2, g2 = mods[s]
+        x = gate_residual(x, p.linear(a, sd[f"{pre}{s}_attn_proj.weight"], sd[f"{pre}{s}_attn_proj.bias"]), g1, p)
+        h = p.linear(ln_modulate(x, sh2, sc2, p), sd[f"{pre}{s}_mlp.fc1.weight"], sd[f"{pre}{s}_mlp.fc1.bias"])
+        h = p.linear(gelu_tanh(h, p), sd[f"{pre}{s}_mlp.fc2.weight"], sd[f"{pre}{s}_mlp.fc2.bias"])
+        outs.append(gate_residual(x, h, g2, p))
+    return outs[0], outs[1]
+
+
+def single_block(sd, pre: str, x: Tensor, vec: Tensor, txt_len: int, cu: Tensor,
+                 cos: Optional[Tensor], sin: Optional[Tensor], heads: int, p: Prec, attn_fn=None) -> Tensor:
+    """MMSingleStreamBlock.forward, modules/models.py:326-393."""
+    attn_fn = attn_fn or attention_varlen
+    d = x.shape[-1]
+    shift, scale, gate = modulation(sd, pre + "modulation.linear.", vec, p).chunk(3, dim=-1)
+    y = p.linear(ln_modulate(x, shift, scale, p), sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])
+    qkv, mlp = y[..., : 3 * d], y[..., 3 * d:]
+    q, k, v = _split_heads(qkv, heads)
+    q = rms_norm(q, sd[pre + "q_norm.weight"], p)
+    k = rms_norm(k, sd[pre + "k_norm.weight"], p)
+    if cos is not None:
+        n_img = x.shape[1] - txt_len
+        q = torch.cat([apply_rope(q[:, :n_img], cos, sin, p), q[:, n_img:]], 1)
+        k = torch.cat([apply_rope(k[:, :n_img], cos, sin, p), k[:, n_img:]], 1)
+    attn = attn_fn(q, k, v, cu, p)
+    out = p.linear(torch.cat([attn, gelu_tanh(mlp, p)], 2), sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
+    return gate_residual(x, out, gate, p)
+
+
+def token_refiner(sd, pre: str, text: Tensor, t: Tensor, mask: Optional[Tensor], heads: int, p: Prec,
+                  depth: int = 2) -> Tensor:
+    """SingleTokenRefiner.forward, modules/token_refiner.py:214-236 with IndividualTokenRefiner
+    :137-161 and its block :77-100 (SDPA with the boolean mask whose column 0 is forced True)."""
+    t_aware = timestep_embedder(sd, pre + "t_embedder.", t, p)
+    if mask is None:
+        ctx = text.float().mean(dim=1)
+    else:
+        mf = mask.float().unsqueeze(-1)
+        ctx = (text.float() * mf).sum(dim=1) / mf.sum(dim=1)
+    ctx = p.linear(ctx, sd[pre + "c_embedder.linear_1.weight"], sd[pre + "c_embedder.linear_1.bias"])
+    ctx = p.linear(p.r(F.silu(ctx)), sd[pre + "c_embedder.linear_2.weight"], sd[pre + "c_embedder.linear_2.bias"])
+    c = p.r(t_aware + ctx)
+    x = p.linear(text, sd[pre + "input_embedder.weight"], sd[pre + "input_embedder.bias"])
+    amask = None
+    if mask is not None:
+        mb = mask.bool()
+        amask = (mb[:, None, None, :] & mb[:, None, :, None]).clone()
+        amask[:, :, :, 0] = True
+    d = x.shape[-1]
+    for i in range(depth):
+        bp = f"{pre}individual_token_refiner.blocks.{i}."
+        g_msa, g_mlp = p.linear(p.r(F.silu(c)), sd[bp + "adaLN_modulation.1.weight"],
+                                sd[bp + "adaLN_modulation.1.bias"]).chunk(2, dim=1)
+        n1 = F.layer_norm(x.float(), (d,), p.r(sd[bp + "norm1.weight"]).float(), p.r(sd[bp + "norm1.bias"]).float(), 1e-6)
+        qkv = p.linear(n1, sd[bp + "self_attn_qkv.weight"], sd[bp + "self_attn_qkv.bias"])
+        q, k, v = _split_heads(qkv, heads)
+        a = sdpa(q, k, v, p, amask).reshape(x.shape[0], x.shape[1], d)
+        x = gate_residual(x, p.linear(a, sd[bp + "self_attn_proj.weight"], sd[bp + "self_attn_proj.bias"]), g_msa, p)
+        n2 = F.layer_norm(x.float(), (d,), p.r(sd[bp + "norm2.weight"]).float(), p.r(sd[bp + "norm2.bias"]).float(), 1e-6)
+        h = p.linear(n2, sd[bp + "mlp.fc1.weight"], sd[bp + "mlp.fc1.bias"])
+        h = p.linear(p.r(F.silu(h)), sd[bp + "mlp.fc2.weight"], sd[bp + "mlp.fc2.bias"])
+        x = gate_residual(x, h, g_mlp, p)
+    return x
+
+
+def patch_embed(sd, x: Tensor, p: Prec) -> Tensor:
+    """PatchEmbed, modules/embed_layers.py:40-59: Conv3d(k=s=patch) then flatten(2).transpose(1,2)."""
+    w = sd["img_in.proj.weight"]
+    y = F.conv3d(p.r(x.float()), p.r(w), p.r(sd["img_in.proj.bias"]), stride=tuple(w.shape[2:]))
+    return p.r(y.flatten(2).transpose(1, 2))
+
+
+def unpatchify(x: Tensor, t: int, h: int, w: int, c: int, patch) -> Tensor:
+    """modules/models.py:697-710."""
+    pt, ph, pw = patch
+    x = x.reshape(x.shape[0], t, h, w, c, pt, ph, pw)
+    x = torch.einsum("nthwcopq->nctohpwq", x)
+    return x.reshape(x.shape[0], c, t * pt, h * ph, w * pw)
+
+
+def final_layer(sd, x: Tensor, vec: Tensor, p: Prec) -> Tensor:
+    """FinalLayer.forward, modules/mlp_layers.py:114-118."""
+    shift, scale = p.linear(p.r(F.silu(vec)), sd["final_layer.adaLN_modulation.1.weight"],
+                            sd["final_layer.adaLN_modulation.1.bias"]).chunk(2, dim=1)
+    return p.linear(ln_modulate(x, shift, scale, p), sd["final_layer.linear.weight"], sd["final_layer.linear.bias"])
+
+
+def dit_vec(sd, t: Tensor, text_states_2: Tensor, guidance: Optional[Tensor], p: Prec) -> Tensor:
+    """modules/models.py:618-631."""
+    vec = timestep_embedder(sd, "time_in.", t, p)
+    h = p.linear(text_states_2, sd["vector_in.in_layer.weight"], sd["vector_in.in_layer.bias"])
+    vec = p.r(vec + p.linear(p.r(F.silu(h)), sd["vector_in.out_layer.weight"], sd["vector_in.out_layer.bias"]))
+    if "guidance_in.mlp.0.weight" in sd:
+        if guidance is None:
+            raise ValueError("Didn't get guidance strength for guidance distilled model.")
+        vec = p.r(vec + timestep_embedder(sd, "guidance_in.", guidance, p))
+    return vec
+
+
+def dit_forward(sd: Dict[str, Tensor], cfg, x: Tensor, t: Tensor, text_states: Tensor, text_mask: Tensor,
+                text_states_2: Tensor, freqs_cos: Optional[Tensor], freqs_sin: Optional[Tensor],
+                guidance: Optional[Tensor], p: Prec = FP32, attn_fn=None, taps: Optional[dict] = None) -> Tensor:
+    """HYVideoDiffusionTransformer.forward, modules/models.py:595-695.  `cfg` is a
+    hunyuanvideo_efficiency_amd.synthetic.DiTConfig (or anything with the same fields)."""
+    _, _, ot, oh, ow = x.shape
+    pt, ph, pw = cfg.patch_size
+    tt, th, tw = ot // pt, oh // ph, ow // pw
+    vec = dit_vec(sd, t, text_states_2, guidance, p)
+    img = patch_embed(sd, x, p)
+    txt = token_refiner(sd, "txt_in.", text_states, t, text_mask, cfg.heads_num, p, cfg.refiner_depth)
+    n_img, n_txt = img.shape[1], txt.shape[1]
+    cu = cu_seqlens(text_mask, n_img)
+    if taps is not None:
+        taps.update(vec=vec, img0=img, txt0=txt, cu=cu)
+    for i in range(cfg.mm_double_blocks_depth):
+        img, txt = double_block(sd, f"double_blocks.{i}.", img, txt, vec, cu, freqs_cos, freqs_sin,
+                                cfg.heads_num, p, attn_fn)
+    if taps is not None:
+        taps.update(img_d=img, txt_d=txt)
+    xs = torch.cat([img, txt], 1)
+    for i in range(cfg.mm_single_blocks_depth):
+        xs = single_block(sd, f"single_blocks.{i}.", xs, vec, n_txt, cu, freqs_cos, freqs_sin,
+                          cfg.heads_num, p, attn_fn)
+    if taps is not None:
+        taps.update(x_s=xs)
+    out = final_layer(sd, xs[:, :n_img], vec, p)
+    return unpatchify(out, tt, th, tw, cfg.out_channels, cfg.patch_size)
+
+
+# ----------------------------------------------------------------------------- scheduler
+def flow_sigmas(n_steps: int, shift: float = 7.0, reverse: bool = True) -> Tensor:
+    """diffusion/schedulers/scheduling_flow_match_discrete.py:144-153,185-186."""
+    s = torch.linspace(1, 0, n_steps + 1)
+    s = (shift * s) / (1 + (shift - 1) * s)
+    return s if reverse else 1 - s
+
+
+def flow_timesteps(sigmas: Tensor, num_train_timesteps: int = 1000) -> Tensor:
+    """scheduling_flow_match_discrete.py:151-153."""
+    return (sigmas[:-1] * num_train_timesteps).to(torch.float32)
+
+
+def euler_step(sample: Tensor, model_output: Tensor, sigmas: Tensor, i: int) -> Tensor:
+    """scheduling_flow_match_discrete.py:236-242: fp32 x + v*(sigma[i+1]-sigma[i])."""
+    dt = sigmas[i + 1] - sigmas[i]
+    return sample.to(torch.float32) + model_output.to(torch.float32) * dt
+
+
+def denoise_loop(sd, cfg, latents: Tensor, n_steps: int, text_states, text_mask, text_states_2,
+                 cos, sin, guidance_scale: float = 6.0, shift: float = 7.0, p: Prec = FP32):
+    """The loop of pipeline_hunyuan_video.py:961-1023 at cfg_scale 1 (no CFG batch):
+    t_expand, guidance = bf16(scale)*1000 (:976-985), transformer, scheduler.step."""
+    sig = flow_sigmas(n_steps, shift)
+    ts = flow_timesteps(sig)
+    # bf16(6.0) * 1000 evaluated in bf16 = 6016
+    g = (torch.tensor([guidance_scale], dtype=torch.float32).to(torch.bfloat16) * 1000.0).to(torch.float32)
+    preds = []
+    for i in range(n_steps):
+        v = dit_forward(sd, cfg, latents, ts[i:i + 1], text_states, text_mask, text_states_2, cos, sin, g, p)
+        preds.append(v)
+        latents = euler_step(latents, v, sig, i)
+    return latents, preds
