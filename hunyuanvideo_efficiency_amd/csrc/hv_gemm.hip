@@ -1,0 +1,213 @@
+// bf16 MFMA GEMM with fused epilogues for the DiT linears (K2, K7, K8, K10, K14-dequantised):
+//     C[M,N] = A[M,K] . W[N,K]^T (+ bias[N])  ->  activation / gated residual / column split
+// Both operands are K-contiguous ("NT"), exactly nn.Linear's layout, so every MFMA fragment is one
+// 16-byte LDS read.  Design for gfx950:
+//   * 256x256x64 tile, 512 threads = 8 waves as 2(M) x 4(N); each wave owns 128x64 outputs as
+//     8x4 v_mfma_f32_16x16x32_bf16 accumulators (128 VGPRs).  The MFMA is issued "swapped"
+//     (D = Wfrag . Afrag^T) so that a lane's 4 accumulator registers are 4 consecutive n of one row m;
+//     the W rows are dealt to MFMA rows in an interleaved order so that two n-repeats give a lane
+//     8 consecutive n -> 16-byte global stores.
+//   * operands stream HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered
+//     (2 x 64 KiB); LDS images are lane-linear as the DMA requires, with the XOR bank swizzle applied
+//     on the SOURCE address and on the read (both-sides rule) -> conflict-free ds_read_b128.
+//   * 1-D grid, remapped so each XCD gets a contiguous chunk of tiles (shared L2) and 32 co-resident
+//     tiles form a 4(M) x 8(N) patch (A and W panels are shared inside an XCD).
+// Algorithmic work: 2*M*N*K flop; HBM bytes >= 2*(M*K + N*K + M*N).
+#include "hv_common.hpp"
+#include "../../include/hv_kernels.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffered: 128 KiB
+constexpr int GROUP_M = 4;
+
+struct GemmArgs {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* W; int64_t ldw;
+    const bf16_t* bias;
+    int M, N, K;
+    bf16_t* out0; int64_t ld0; int act0;
+    int n_split;
+    bf16_t* out1; int64_t ld1; int act1;
+    const bf16_t* gate;
+    const bf16_t* res; int64_t ld_res;
+    int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ int swz_a(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int swz_w(int row) { return (((row >> 3) & 3) << 1) | ((row >> 1) & 1); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return gelu_tanh_f(v);
+    if (act == 2) return silu_f(v);
+    return v;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // ---- XCD-aware tile mapping (bijective for any grid size)
+    const int nwg = gridDim.x;
+    int lin;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int band = lin / (GROUP_M * g.tiles_n), rem = lin % (GROUP_M * g.tiles_n);
+    const int band_m0 = band * GROUP_M;
+    const int gm = min(GROUP_M, g.tiles_m - band_m0);
+    const int tm = band_m0 + rem % gm, tn = rem / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-thread staging addresses: 4 DMA pieces per operand per K-tile, each 512 thr x 16 B = 64 rows
+    const int srow = tid >> 3, scp = tid & 7;  // row within a 64-row piece, 16-B chunk position in LDS
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 64 + srow;
+        const int ar = min(m0 + row, g.M - 1), wr = min(n0 + row, g.N - 1);  // clamp: tails read valid rows
+        a_src[i] = g.A + (int64_t)ar * g.lda + ((scp ^ swz_a(row)) << 3);
+        w_src[i] = g.W + (int64_t)wr * g.ldw + ((scp ^ swz_w(row)) << 3);
+    }
+    const int wave_lds = wave * 1024;  // wave-uniform base of this wave's 1 KiB slice of each piece
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES + wave_lds;
+        const int koff = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + koff), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + koff), (lds_ptr_t)(base + TILE_BYTES + i * 8192), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside an operand tile), k-step 0; k-step 1 flips chunk bit 2
+    const int fr = lane & 15, fq = lane >> 4;
+    int a_off[8], w_off[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int row = wm * 128 + mi * 16 + fr;
+        a_off[mi] = row * 128 + ((fq ^ swz_a(row)) << 4);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        // MFMA row i of n-repeat ni holds W row: (ni>>1)*32 + (i>>2)*8 + (ni&1)*4 + (i&3)
+        const int row = wn * 64 + (ni >> 1) * 32 + (fr >> 2) * 8 + (ni & 1) * 4 + (fr & 3);
+        w_off[ni] = row * 128 + ((fq ^ swz_w(row)) << 4);
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = g.K / BK;
+    stage(0, 0);
+    __syncthreads();  // (the compiler drains vmcnt before the barrier: DMA landed)
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+        const char* At = smem + buf * STAGE_BYTES;
+        const char* Wt = At + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[8], wf[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(Wt + (w_off[ni] ^ (ks << 6)));
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(At + (a_off[mi] ^ (ks << 6)));
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, per (mi, n-repeat pair), 8 consecutive n of row m
+    const int mrow0 = m0 + wm * 128 + fr;
+#pragma unroll
+    for (int np = 0; np < 2; ++np) {
+        const int n = n0 + wn * 64 + np * 32 + fq * 8;
+        if (n >= g.N) continue;
+        float b[8], gt[8];
+        if (g.bias) unpack8(*reinterpret_cast<const u32x4*>(g.bias + n), b);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = 0.f;
+        }
+        if (g.gate) unpack8(*reinterpret_cast<const u32x4*>(g.gate + n), gt);
+        const bool second = n >= g.n_split;
+        bf16_t* obase = second ? g.out1 + (n - g.n_split) : g.out0 + n;
+        const int64_t ldo = second ? g.ld1 : g.ld0;
+        const int act = second ? g.act1 : g.act0;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = mrow0 + mi * 16;
+            if (m >= g.M) continue;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[mi][2 * np][r] + b[r];
+                v[4 + r] = acc[mi][2 * np + 1][r] + b[4 + r];
+            }
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = apply_act(rbf(v[j]), act);
+            }
+            if (g.gate) {
+                float rs[8];
+                unpack8(*reinterpret_cast<const u32x4*>(g.res + (int64_t)m * g.ld_res + n), rs);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = rs[j] + rbf(rbf(v[j]) * gt[j]);
+            }
+            *reinterpret_cast<u32x4*>(obase + (int64_t)m * ldo) = pack8(v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int hv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, int M, int N, int K,
+                            void* out0, int64_t ld0, int act0, int n_split, void* out1, int64_t ld1, int act1,
+                            const void* gate, const void* res, int64_t ld_res, hipStream_t stream) {
+    if (!A || !W || !out0 || M < 0 || N <= 0 || K < BK || (K % BK) || (N & 7) || (lda & 7) || (ldw & 7) || (ld0 & 7))
+        return HV_ERR_ARG;
+    if (n_split <= 0 || n_split > N) n_split = N;
+    if (n_split < N && (!out1 || (n_split & 7) || (ld1 & 7))) return HV_ERR_ARG;
+    if ((gate != nullptr) != (res != nullptr) || (res && (ld_res & 7))) return HV_ERR_ARG;
+    if (act0 < 0 || act0 > 2 || act1 < 0 || act1 > 2) return HV_ERR_ARG;
+    if (M == 0) return HV_OK;
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = (const bf16_t*)bias;
+    g.M = M; g.N = N; g.K = K;
+    g.out0 = (bf16_t*)out0; g.ld0 = ld0; g.act0 = act0; g.n_split = n_split;
+    g.out1 = (bf16_t*)out1; g.ld1 = ld1; g.act1 = act1;
+    g.gate = (const bf16_t*)gate; g.res = (const bf16_t*)res; g.ld_res = ld_res;
+    g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return HV_ERR_LAUNCH;
+        attr_set = true;
+    }
+    gemm_bf16_kernel<<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS_BYTES, stream>>>(g);
+    return hv_check_launch();
+}

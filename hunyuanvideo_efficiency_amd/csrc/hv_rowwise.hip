@@ -1,0 +1,322 @@
+// HBM-bound row-wise kernels of the DiT block: LayerNorm + adaLN modulate (K1), per-head RMSNorm +
+// 3D RoPE applied in place on the fused QKV rows (K3+K4, which also removes the concat K5), the
+// small-M linear (GEMV) used for every `vec`-only projection (K9/K11), and the token/latent
+// reshuffles (K10 gather, unpatchify, Euler step K13).  All loads/stores are 16 B per lane.
+#include "hv_common.hpp"
+#include "../../include/hv_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm(no affine) * mul + add.   mode 0: mul = bf16(1 + scale[d]), add = shift[d]  (adaLN modulate)
+//                                      mode 1: mul = weight[d],          add = bias[d]   (affine LN)
+// One wave per row, the row lives in registers (D <= 4096, D % 8 == 0).  Two-pass mean/variance in fp32.
+template <int MAXC>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ add,
+                                                      const bf16_t* __restrict__ mul, bf16_t* __restrict__ out,
+                                                      int64_t M, int D, int64_t ldx, int64_t ldo, float eps, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nchunk = D >> 3;
+    const bf16_t* xr = x + row * ldx;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            u32x4 w = *reinterpret_cast<const u32x4*>(xr + ch * 8);
+            unpack8(w, v[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[c][j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float d = v[c][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    bf16_t* orow = out + row * ldo;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            float m[8], a[8], o[8];
+            if (mul) {
+                unpack8(*reinterpret_cast<const u32x4*>(mul + ch * 8), m);
+                if (mode == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m[j] = rbf(1.0f + m[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = 1.0f;
+            }
+            if (add) {
+                unpack8(*reinterpret_cast<const u32x4*>(add + ch * 8), a);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * m[j] + a[j];
+            *reinterpret_cast<u32x4*>(orow + ch * 8) = pack8(o);
+        }
+    }
+}
+
+extern "C" int hv_ln_modulate_bf16(const void* x, const void* shift_or_bias, const void* scale_or_weight, void* out,
+                                   int64_t M, int D, int64_t ldx, int64_t ldo, float eps, int mode, hipStream_t stream) {
+    if (!x || !out || M < 0 || D <= 0 || (D & 7) || D > 4096 || (ldx & 7) || (ldo & 7) || (mode != 0 && mode != 1))
+        return HV_ERR_ARG;
+    if (M == 0) return HV_OK;
+    dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    const bf16_t *xp = (const bf16_t*)x, *ap = (const bf16_t*)shift_or_bias, *mp = (const bf16_t*)scale_or_weight;
+    if (D <= 512)
+        ln_mod_kernel<1><<<grid, block, 0, stream>>>(xp, ap, mp, (bf16_t*)out, M, D, ldx, ldo, eps, mode);
+    else if (D <= 2048)
+        ln_mod_kernel<4><<<grid, block, 0, stream>>>(xp, ap, mp, (bf16_t*)out, M, D, ldx, ldo, eps, mode);
+    else if (D <= 3072)
+        ln_mod_kernel<6><<<grid, block, 0, stream>>>(xp, ap, mp, (bf16_t*)out, M, D, ldx, ldo, eps, mode);
+    else
+        ln_mod_kernel<8><<<grid, block, 0, stream>>>(xp, ap, mp, (bf16_t*)out, M, D, ldx, ldo, eps, mode);
+    return hv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-place per-head RMSNorm (+ RoPE) of the q and k thirds of fused QKV rows [n_rows, ld], head_dim 128.
+//   y = bf16( x_f32 * rsqrt(mean(x^2)+eps) )  -> y = bf16(y * w)     (cast BEFORE the gain, norm_layers.py:56-58)
+//   rope rows (row < n_rope): out[2i]   = y[2i]*cos[2i]   - y[2i+1]*sin[2i]
+//                             out[2i+1] = y[2i+1]*cos[2i+1] + y[2i]*sin[2i+1]     (fp32, one rounding)
+// 16 lanes own one 128-wide head vector (8 elements = 4 RoPE pairs per lane).
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qw,
+                                                           const bf16_t* __restrict__ kw, const float* __restrict__ cosT,
+                                                           const float* __restrict__ sinT, int64_t n_rows, int64_t n_rope,
+                                                           int H, int64_t ld, int64_t k_off, float eps) {
+    const int64_t row = blockIdx.x;
+    const int sub = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;  // 16 groups
+    float wq[8], wk[8], c[8], s[8];
+    unpack8(*reinterpret_cast<const u32x4*>(qw + sub * 8), wq);
+    unpack8(*reinterpret_cast<const u32x4*>(kw + sub * 8), wk);
+    const bool rope = row < n_rope;
+    if (rope) {
+        const float4* cp = reinterpret_cast<const float4*>(cosT + row * 128 + sub * 8);
+        const float4* sp = reinterpret_cast<const float4*>(sinT + row * 128 + sub * 8);
+        float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+        c[0] = c0.x, c[1] = c0.y, c[2] = c0.z, c[3] = c0.w, c[4] = c1.x, c[5] = c1.y, c[6] = c1.z, c[7] = c1.w;
+        s[0] = s0.x, s[1] = s0.y, s[2] = s0.z, s[3] = s0.w, s[4] = s1.x, s[5] = s1.y, s[6] = s1.z, s[7] = s1.w;
+    }
+    for (int hv = grp; hv < 2 * H; hv += 16) {
+        const bool is_k = hv >= H;
+        const int h = is_k ? hv - H : hv;
+        bf16_t* p = qkv + row * ld + (is_k ? k_off : 0) + h * 128 + sub * 8;
+        float x[8];
+        unpack8(*reinterpret_cast<const u32x4*>(p), x);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 16);
+        const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(x[j] * r) * (is_k ? wk[j] : wq[j]));
+        if (rope) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                o[j] = y[j] * c[j] - y[j + 1] * s[j];
+                o[j + 1] = y[j + 1] * c[j + 1] + y[j] * s[j + 1];
+            }
+            *reinterpret_cast<u32x4*>(p) = pack8(o);
+        } else {
+            *reinterpret_cast<u32x4*>(p) = pack8(y);
+        }
+    }
+}
+
+extern "C" int hv_qknorm_rope_bf16(void* qkv, const void* q_weight, const void* k_weight, const float* cos_tab,
+                                   const float* sin_tab, int64_t n_rows, int64_t n_rope, int n_heads, int head_dim,
+                                   int64_t ld, int64_t k_offset, float eps, hipStream_t stream) {
+    if (!qkv || !q_weight || !k_weight || head_dim != 128 || n_heads <= 0 || n_rows < 0 || n_rope < 0 ||
+        n_rope > n_rows || (ld & 7) || (k_offset & 7) || (n_rope > 0 && (!cos_tab || !sin_tab)))
+        return HV_ERR_ARG;
+    if (n_rows == 0) return HV_OK;
+    qknorm_rope_kernel<<<dim3((unsigned)n_rows), dim3(256), 0, stream>>>((bf16_t*)qkv, (const bf16_t*)q_weight,
+                                                                          (const bf16_t*)k_weight, cos_tab, sin_tab, n_rows,
+                                                                          n_rope, n_heads, ld, k_offset, eps);
+    return hv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small-M linear: out[m][n] = act_out( sum_k act_in(x[m][k]) * W[n][k] + b[n] ), M <= 4.  One wave per output
+// column n, W streamed once (HBM-bound).  act flags: bit0 = SiLU on the input (rounded to bf16 as the reference's
+// bf16 SiLU does), bit1 = SiLU on the output (applied to the bf16-rounded sum, rounded again).
+template <int MM>
+__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                    const bf16_t* __restrict__ b, bf16_t* __restrict__ out, int N, int K,
+                                                    int64_t ldx, int64_t ldo, int act) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+    const bf16_t* wr = W + (int64_t)n * K;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+        float w[8];
+        unpack8(*reinterpret_cast<const u32x4*>(wr + k0), w);
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            float xv[8];
+            unpack8(*reinterpret_cast<const u32x4*>(x + m * ldx + k0), xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = xv[j];
+                if (act & 1) a = rbf(silu_f(a));
+                acc[m] += a * w[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        float r = wave_sum(acc[m]);
+        if (lane == 0) {
+            if (b) r += bf2f(b[n]);
+            if (act & 2) r = silu_f(rbf(r));
+            out[m * ldo + n] = f2bf(r);
+        }
+    }
+}
+
+extern "C" int hv_linear_smallm_bf16(const void* x, const void* W, const void* bias, void* out, int M, int N, int K,
+                                     int64_t ldx, int64_t ldo, int act, hipStream_t stream) {
+    if (!x || !W || !out || M < 1 || M > 4 || N < 1 || K < 8 || (K & 7) || (ldx & 7)) return HV_ERR_ARG;
+    dim3 grid((N + 3) / 4), block(256);
+    const bf16_t *xp = (const bf16_t*)x, *wp = (const bf16_t*)W, *bp = (const bf16_t*)bias;
+    bf16_t* op = (bf16_t*)out;
+    switch (M) {
+        case 1: gemv_kernel<1><<<grid, block, 0, stream>>>(xp, wp, bp, op, N, K, ldx, ldo, act); break;
+        case 2: gemv_kernel<2><<<grid, block, 0, stream>>>(xp, wp, bp, op, N, K, ldx, ldo, act); break;
+        case 3: gemv_kernel<3><<<grid, block, 0, stream>>>(xp, wp, bp, op, N, K, ldx, ldo, act); break;
+        default: gemv_kernel<4><<<grid, block, 0, stream>>>(xp, wp, bp, op, N, K, ldx, ldo, act); break;
+    }
+    return hv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Latent -> patch rows: A[tok][c*4 + ph*2 + pw] = bf16(x[c][t][2h+ph][2w+pw]), tok = (t*Hp + h)*Wp + w
+// (PatchEmbed's Conv3d k=s=(1,2,2) as a K=64 GEMM, embed_layers.py:40-59).  x is fp32 [C,T,H,W] (C*4 == 64).
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, bf16_t* __restrict__ A, int C, int T,
+                                                        int H, int W) {
+    const int Hp = H >> 1, Wp = W >> 1;
+    const int64_t ntok = (int64_t)T * Hp * Wp;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (tok, c) per thread
+    if (idx >= ntok * C) return;
+    const int c = (int)(idx % C);
+    const int64_t tok = idx / C;
+    const int w = (int)(tok % Wp), h = (int)((tok / Wp) % Hp), t = (int)(tok / ((int64_t)Wp * Hp));
+    const float* p = x + (((int64_t)c * T + t) * H + 2 * h) * W + 2 * w;
+    float2 r0 = *reinterpret_cast<const float2*>(p);
+    float2 r1 = *reinterpret_cast<const float2*>(p + W);
+    u32x2 o;
+    o[0] = pack_bf2(r0.x, r0.y);
+    o[1] = pack_bf2(r1.x, r1.y);
+    *reinterpret_cast<u32x2*>(A + tok * (C * 4) + c * 4) = o;
+}
+
+extern "C" int hv_patchify_f32_bf16(const float* x, void* A, int C, int T, int H, int W, hipStream_t stream) {
+    if (!x || !A || C <= 0 || T <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return HV_ERR_ARG;
+    const int64_t n = (int64_t)T * (H / 2) * (W / 2) * C;
+    patchify_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(x, (bf16_t*)A, C, T, H, W);
+    return hv_check_launch();
+}
+
+// unpatchify (models.py:697-710): y[tok][c*4+ph*2+pw] -> out[c][t][2h+ph][2w+pw]  (bf16 -> bf16)
+__global__ __launch_bounds__(256) void unpatchify_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ out, int C,
+                                                          int T, int H, int W, int64_t ldy) {
+    const int Hp = H >> 1, Wp = W >> 1;
+    const int64_t ntok = (int64_t)T * Hp * Wp;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ntok * C) return;
+    const int64_t tok = idx % ntok;  // consecutive threads -> consecutive w: coalesced writes
+    const int c = (int)(idx / ntok);
+    const int w = (int)(tok % Wp), h = (int)((tok / Wp) % Hp), t = (int)(tok / ((int64_t)Wp * Hp));
+    u32x2 v = *reinterpret_cast<const u32x2*>(y + tok * ldy + c * 4);
+    bf16_t* p = out + (((int64_t)c * T + t) * H + 2 * h) * W + 2 * w;
+    *reinterpret_cast<uint32_t*>(p) = v[0];
+    *reinterpret_cast<uint32_t*>(p + W) = v[1];
+}
+
+extern "C" int hv_unpatchify_bf16(const void* y, void* out, int C, int T, int H, int W, int64_t ldy, hipStream_t stream) {
+    if (!y || !out || C <= 0 || T <= 0 || (H & 1) || (W & 1) || (ldy & 3)) return HV_ERR_ARG;
+    const int64_t n = (int64_t)T * (H / 2) * (W / 2) * C;
+    unpatchify_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>((const bf16_t*)y, (bf16_t*)out, C, T, H,
+                                                                                  W, ldy);
+    return hv_check_launch();
+}
+
+// Euler step (scheduling_flow_match_discrete.py:236-242): sample_f32 += f32(v_bf16) * dt
+__global__ __launch_bounds__(256) void euler_kernel(float* __restrict__ s, const bf16_t* __restrict__ v, float dt, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 a = *reinterpret_cast<float4*>(s + i);
+        u32x2 w = *reinterpret_cast<const u32x2*>(v + i);
+        a.x += bf2f_lo(w[0]) * dt, a.y += bf2f_hi(w[0]) * dt, a.z += bf2f_lo(w[1]) * dt, a.w += bf2f_hi(w[1]) * dt;
+        *reinterpret_cast<float4*>(s + i) = a;
+    } else {
+        for (int64_t j = i; j < n; ++j) s[j] += bf2f(v[j]) * dt;
+    }
+}
+
+extern "C" int hv_euler_step_f32(float* sample, const void* model_out_bf16, float dt, int64_t n, hipStream_t stream) {
+    if (!sample || !model_out_bf16 || n < 0) return HV_ERR_ARG;
+    if (n == 0) return HV_OK;
+    euler_kernel<<<dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, stream>>>(sample, (const bf16_t*)model_out_bf16, dt, n);
+    return hv_check_launch();
+}
+
+// masked mean over tokens (token_refiner.py:222-228): out[d] = sum_l x[l][d]*mask[l] / sum_l mask[l], fp32 -> bf16 out
+__global__ __launch_bounds__(256) void masked_mean_kernel(const bf16_t* __restrict__ x, const int* __restrict__ mask,
+                                                           bf16_t* __restrict__ out, int L, int D) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float s = 0.f, c = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const float m = mask ? (float)mask[l] : 1.0f;
+        s += bf2f(x[(int64_t)l * D + d]) * m;
+        c += m;
+    }
+    out[d] = f2bf(s / c);
+}
+
+extern "C" int hv_masked_mean_bf16(const void* x, const int* mask, void* out, int L, int D, hipStream_t stream) {
+    if (!x || !out || L <= 0 || D <= 0) return HV_ERR_ARG;
+    masked_mean_kernel<<<dim3((D + 255) / 256), dim3(256), 0, stream>>>((const bf16_t*)x, mask, (bf16_t*)out, L, D);
+    return hv_check_launch();
+}
+
+// broadcast one row into n rows (token refiner: fully-masked query rows attend only key 0 -> out = v[0])
+__global__ __launch_bounds__(256) void bcast_row_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int64_t n,
+                                                         int D, int64_t ld) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    dst[(i / D) * ld + (i % D)] = src[i % D];
+}
+
+extern "C" int hv_broadcast_row_bf16(const void* src, void* dst, int64_t n_rows, int D, int64_t ld, hipStream_t stream) {
+    if (!src || !dst || n_rows < 0 || D <= 0) return HV_ERR_ARG;
+    if (n_rows == 0) return HV_OK;
+    bcast_row_kernel<<<dim3((unsigned)((n_rows * D + 255) / 256)), dim3(256), 0, stream>>>((const bf16_t*)src, (bf16_t*)dst,
+                                                                                          n_rows, D, ld);
+    return hv_check_launch();
+}

@@ -1,0 +1,186 @@
+"""Tensor-level wrappers over the C ABI (include/hv_kernels.h).  torch supplies device memory and the
+current HIP stream only; every arithmetic operation is a hand-written gfx950 kernel.  All wrappers
+raise if given a non-GPU tensor: there is no CPU path in the product."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str, last_contig: bool = True):
+    if not t.is_cuda:
+        raise _lib.HVKernelError(f"{name}: expected a GPU tensor (this package has no CPU path), got {t.device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if last_contig and t.dim() > 0 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+
+
+def _rows(t: torch.Tensor, name: str):
+    """view a [.., D] tensor as rows: returns (n_rows, D, row_stride); leading dims must be collapsible"""
+    if t.dim() == 1:
+        return 1, t.shape[0], t.shape[0]
+    d = t.shape[-1]
+    n = t.numel() // d
+    ld = t.stride(-2)
+    # every leading dim must be a multiple walk of ld
+    exp = ld
+    for i in range(t.dim() - 2, -1, -1):
+        if t.shape[i] != 1 and t.stride(i) != exp:
+            raise ValueError(f"{name}: rows are not uniformly strided {t.shape} {t.stride()}")
+        exp *= t.shape[i]
+    return n, d, ld
+
+
+def ln_modulate(x, shift=None, scale=None, out=None, eps: float = 1e-6, affine: bool = False):
+    """mode 0: LN(x)*bf16(1+scale)+shift ; affine=True: LN(x)*scale(weight)+shift(bias)."""
+    _chk(x, BF16, "x")
+    m, d, ldx = _rows(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _chk(out, BF16, "out")
+    mo, do, ldo = _rows(out, "out")
+    assert (mo, do) == (m, d)
+    for t, n in ((shift, "shift"), (scale, "scale")):
+        if t is not None:
+            _chk(t, BF16, n)
+            assert t.numel() == d and t.is_contiguous(), f"{n} must be a contiguous [{d}] vector (batch 1)"
+    _lib.check(_lib.load().hv_ln_modulate_bf16(_ptr(x), _ptr(shift), _ptr(scale), _ptr(out), m, d, ldx, ldo, eps,
+                                               1 if affine else 0, _stream()), "hv_ln_modulate_bf16")
+    return out
+
+
+def qknorm_rope_(qkv, q_weight, k_weight, cos, sin, n_rope: int, n_heads: int, k_offset: int, eps: float = 1e-6):
+    """in place on qkv rows [n_rows, ld]: RMSNorm(q), RMSNorm(k) per head, RoPE on rows [0, n_rope)."""
+    _chk(qkv, BF16, "qkv")
+    n, _, ld = _rows(qkv, "qkv")
+    _chk(q_weight, BF16, "q_weight"), _chk(k_weight, BF16, "k_weight")
+    if n_rope > 0:
+        _chk(cos, torch.float32, "cos"), _chk(sin, torch.float32, "sin")
+        assert cos.is_contiguous() and sin.is_contiguous() and cos.shape[-1] == 128 and cos.shape[0] >= n_rope
+    _lib.check(_lib.load().hv_qknorm_rope_bf16(_ptr(qkv), _ptr(q_weight), _ptr(k_weight), _ptr(cos), _ptr(sin), n,
+                                               n_rope, n_heads, 128, ld, k_offset, eps, _stream()), "hv_qknorm_rope_bf16")
+    return qkv
+
+
+def gemm(a, w, bias=None, out=None, act: int = ACT_NONE, n_split: int = 0, out1=None, act1: int = ACT_NONE,
+         gate=None, res=None):
+    """out = a @ w.T + bias with the fused epilogues of hv_gemm_bf16.  a:[M,K] w:[N,K] (row strides free)."""
+    _chk(a, BF16, "a"), _chk(w, BF16, "w")
+    m, k, lda = _rows(a, "a")
+    n, kw, ldw = _rows(w, "w")
+    assert k == kw, (a.shape, w.shape)
+    n0 = n_split if 0 < n_split < n else n
+    if out is None:
+        out = torch.empty(*a.shape[:-1], n0, dtype=BF16, device=a.device)
+    _chk(out, BF16, "out")
+    mo, no, ld0 = _rows(out, "out")
+    assert mo == m and no >= n0
+    ld1 = 0
+    if n0 < n:
+        _chk(out1, BF16, "out1")
+        m1, n1, ld1 = _rows(out1, "out1")
+        assert m1 == m and n1 >= n - n0
+    for t, nm in ((bias, "bias"), (gate, "gate")):
+        if t is not None:
+            _chk(t, BF16, nm)
+            assert t.numel() == n and t.is_contiguous()
+    ld_res = 0
+    if res is not None:
+        _chk(res, BF16, "res")
+        mr, nr, ld_res = _rows(res, "res")
+        assert mr == m and nr == n
+    _lib.check(_lib.load().hv_gemm_bf16(_ptr(a), lda, _ptr(w), ldw, _ptr(bias), m, n, k, _ptr(out), ld0, act, n0,
+                                        _ptr(out1), ld1, act1, _ptr(gate), _ptr(res), ld_res, _stream()), "hv_gemm_bf16")
+    return out
+
+
+def linear_smallm(x, w, bias=None, silu_in: bool = False, silu_out: bool = False, out=None):
+    _chk(x, BF16, "x"), _chk(w, BF16, "w")
+    m, k, ldx = _rows(x, "x")
+    n, kw, ldw = _rows(w, "w")
+    assert k == kw and ldw == k and m <= 4
+    if out is None:
+        out = torch.empty(*x.shape[:-1], n, dtype=BF16, device=x.device)
+    _, _, ldo = _rows(out, "out")
+    if bias is not None:
+        _chk(bias, BF16, "bias")
+    _lib.check(_lib.load().hv_linear_smallm_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), m, n, k, ldx, ldo,
+                                                 (1 if silu_in else 0) | (2 if silu_out else 0), _stream()),
+               "hv_linear_smallm_bf16")
+    return out
+
+
+def attn_fwd(q, k, v, out, n_heads: int, scale: Optional[float] = None):
+    """q:[n_q, >=H*128] k,v:[n_kv, ...] out:[n_q, ...] 2-D views (token rows, head h at column h*128)."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
+        _chk(t, BF16, nm)
+        assert t.dim() == 2
+    n_q, n_kv = q.shape[0], k.shape[0]
+    assert v.shape[0] == n_kv and out.shape[0] == n_q
+    if scale is None:
+        scale = 128 ** -0.5
+    _lib.check(_lib.load().hv_attn_fwd_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), q.stride(0), k.stride(0), v.stride(0),
+                                            out.stride(0), n_q, n_kv, n_heads, 128, scale, _stream()), "hv_attn_fwd_bf16")
+    return out
+
+
+def patchify(x_f32, out=None):
+    """x:[C,T,H,W] fp32 -> [T*(H/2)*(W/2), C*4] bf16"""
+    _chk(x_f32, torch.float32, "x")
+    assert x_f32.is_contiguous() and x_f32.dim() == 4
+    c, t, h, w = x_f32.shape
+    if out is None:
+        out = torch.empty(t * (h // 2) * (w // 2), c * 4, dtype=BF16, device=x_f32.device)
+    _lib.check(_lib.load().hv_patchify_f32_bf16(_ptr(x_f32), _ptr(out), c, t, h, w, _stream()), "hv_patchify_f32_bf16")
+    return out
+
+
+def unpatchify(y, c: int, t: int, h: int, w: int, out=None):
+    _chk(y, BF16, "y")
+    assert y.dim() == 2
+    if out is None:
+        out = torch.empty(c, t, h, w, dtype=BF16, device=y.device)
+    _lib.check(_lib.load().hv_unpatchify_bf16(_ptr(y), _ptr(out), c, t, h, w, y.stride(0), _stream()), "hv_unpatchify_bf16")
+    return out
+
+
+def euler_step_(sample_f32, model_out_bf16, dt: float):
+    _chk(sample_f32, torch.float32, "sample"), _chk(model_out_bf16, BF16, "model_out")
+    assert sample_f32.is_contiguous() and model_out_bf16.is_contiguous() and sample_f32.numel() == model_out_bf16.numel()
+    _lib.check(_lib.load().hv_euler_step_f32(_ptr(sample_f32), _ptr(model_out_bf16), float(dt), sample_f32.numel(),
+                                             _stream()), "hv_euler_step_f32")
+    return sample_f32
+
+
+def masked_mean(x, mask_i32=None):
+    _chk(x, BF16, "x")
+    assert x.dim() == 2 and x.is_contiguous()
+    out = torch.empty(x.shape[1], dtype=BF16, device=x.device)
+    if mask_i32 is not None:
+        _chk(mask_i32, torch.int32, "mask")
+    _lib.check(_lib.load().hv_masked_mean_bf16(_ptr(x), _ptr(mask_i32), _ptr(out), x.shape[0], x.shape[1], _stream()),
+               "hv_masked_mean_bf16")
+    return out
+
+
+def broadcast_row_(src, dst):
+    _chk(src, BF16, "src"), _chk(dst, BF16, "dst")
+    assert dst.dim() == 2 and src.numel() == dst.shape[1]
+    _lib.check(_lib.load().hv_broadcast_row_bf16(_ptr(src), _ptr(dst), dst.shape[0], dst.shape[1], dst.stride(0), _stream()),
+               "hv_broadcast_row_bf16")
+    return dst

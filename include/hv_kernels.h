@@ -1,0 +1,90 @@
+/* C ABI of libhv_kernels.so: the MI355X (gfx950) kernels behind the HunyuanVideo denoise / VAE-decode
+ * hot path.  Plain pointers + sizes + a hipStream_t; no allocation inside, caller owns every buffer;
+ * work is enqueued on `stream` and the call returns immediately.  Return: 0 = HV_OK, -1 = bad
+ * argument (nothing launched), -2 = launch failure.  bf16 tensors are raw 16-bit words ("void*").
+ *
+ * The reference (c976237222/HunyuanVideo_efficiency) has no FFI of its own; its seams are Python call
+ * sites.  Each entry point below names the reference arithmetic it replaces
+ * (paths relative to /root/reference/hyvideo/).  The Python host side that mirrors the reference
+ * interface (the modules/ directory of the hunyuanvideo_efficiency_amd package) binds these symbols with ctypes;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ */
+#ifndef HV_KERNELS_H
+#define HV_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+/* ABI version of this header (bumped on any signature change). */
+int hv_abi_version(void);
+
+/* K1: nn.LayerNorm(elementwise_affine=False, eps) followed by modulate()
+ *     (modules/models.py:161-164,182-185,235,246,338; modules/modulate_layers.py:31-49; mlp_layers.py:115-117)
+ * mode 0: out = LN(x) * bf16(1 + scale[d]) + shift[d]      (shift/scale may be NULL = absent)
+ * mode 1: out = LN(x) * weight[d] + bias[d]                (token_refiner.py:33-35,56-58 affine LayerNorm)
+ * x/out: [M, D] bf16 with row strides ldx/ldo (elements); D % 8 == 0, D <= 4096. */
+int hv_ln_modulate_bf16(const void* x, const void* shift_or_bias, const void* scale_or_weight, void* out,
+                        int64_t M, int D, int64_t ldx, int64_t ldo, float eps, int mode, hipStream_t stream);
+
+/* K3+K4(+K5): per-head RMSNorm of q and k (modules/norm_layers.py:43,56-59) and apply_rotary_emb
+ * (modules/posemb_layers.py:133-137,165-171) IN PLACE on fused QKV rows:
+ *   row r: q head h at qkv[r*ld + h*128], k head h at qkv[r*ld + k_offset + h*128]  (v untouched).
+ * Rows [0, n_rope) are rotated with cos/sin[r][128] (fp32); rows [n_rope, n_rows) are only normalised
+ * (text tokens).  Writing in place into the joint [img|txt] QKV buffer removes the torch.cat of
+ * models.py:195-197,358-359. head_dim must be 128. */
+int hv_qknorm_rope_bf16(void* qkv, const void* q_weight, const void* k_weight, const float* cos_tab,
+                        const float* sin_tab, int64_t n_rows, int64_t n_rope, int n_heads, int head_dim,
+                        int64_t ld, int64_t k_offset, float eps, hipStream_t stream);
+
+/* K2/K7/K8/K10: nn.Linear on MFMA with fused epilogue.  C = A[M,K] . W[N,K]^T + bias
+ *   (models.py:165,186,231,242,339-341,392-393; mlp_layers.py:53-59,117; embed_layers.py:40-59)
+ * Columns [0, n_split) go to out0 (row stride ld0) with activation act0, columns [n_split, N) to
+ * out1[., n - n_split] (row stride ld1) with act1 (act: 0 none, 1 GELU-tanh, 2 SiLU) - the single-stream
+ * block's linear1 split + mlp_act (models.py:339-341,392).  n_split <= 0 or >= N: no split.
+ * If gate != NULL: out = res + bf16(bf16(y) * gate[n])  (x + apply_gate(y, gate), models.py:231-250,393);
+ * res may alias out0.  K % 64 == 0, N % 8 == 0, all strides % 8 == 0. */
+int hv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, int M, int N, int K,
+                 void* out0, int64_t ld0, int act0, int n_split, void* out1, int64_t ld1, int act1,
+                 const void* gate, const void* res, int64_t ld_res, hipStream_t stream);
+
+/* K9/K11: small-M Linear (M <= 4): out = act_out(W . act_in(x) + b).  act bit0: SiLU on input
+ * (ModulateDiT / adaLN: Linear(SiLU(vec)), modulate_layers.py:27-28), bit1: SiLU on output
+ * (MLPEmbedder / TimestepEmbedder hidden layer, mlp_layers.py:72-73, embed_layers.py:140-150). */
+int hv_linear_smallm_bf16(const void* x, const void* W, const void* bias, void* out, int M, int N, int K,
+                          int64_t ldx, int64_t ldo, int act, hipStream_t stream);
+
+/* K6/K6': softmax(scale * q k^T) v, bf16, head_dim 128, non-causal, over ONE contiguous key segment
+ * (flash_attn_varlen_func / _flash_attn_forward of modules/attenion.py:107-120,181-207: the caller
+ * issues one call per cu_seqlens segment).  q/k/v/o: token-major, head h at column h*128 of each row;
+ * strides in elements (so q,k,v may point into one fused QKV buffer and o into a wider concat buffer). */
+int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t stride_q, int64_t stride_k,
+                     int64_t stride_v, int64_t stride_o, int n_q, int n_kv, int n_heads, int head_dim,
+                     float scale, hipStream_t stream);
+
+/* K10 gather: fp32 latent [C,T,H,W] -> bf16 patch rows [T*(H/2)*(W/2), C*4] (embed_layers.py:40-59). */
+int hv_patchify_f32_bf16(const float* x, void* A, int C, int T, int H, int W, hipStream_t stream);
+
+/* unpatchify (models.py:697-710): y[tok][c*4+ph*2+pw] (row stride ldy) -> out[C,T,H,W] bf16. */
+int hv_unpatchify_bf16(const void* y, void* out, int C, int T, int H, int W, int64_t ldy, hipStream_t stream);
+
+/* K13: FlowMatchDiscreteScheduler.step (scheduling_flow_match_discrete.py:236-242):
+ * sample_f32[i] += f32(model_out_bf16[i]) * dt. */
+int hv_euler_step_f32(float* sample, const void* model_out_bf16, float dt, int64_t n, hipStream_t stream);
+
+/* token_refiner.py:222-228: out[d] = sum_l x[l][d]*mask[l] / sum_l mask[l]  (mask NULL = plain mean). */
+int hv_masked_mean_bf16(const void* x, const int* mask, void* out, int L, int D, hipStream_t stream);
+
+/* token_refiner.py:155-157: fully masked query rows see only key 0 -> their attention output is v[0]. */
+int hv_broadcast_row_bf16(const void* src, void* dst, int64_t n_rows, int D, int64_t ld, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HV_KERNELS_H */

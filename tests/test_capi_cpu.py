@@ -1,0 +1,45 @@
+"""CPU: the C-ABI library loads and exports exactly the symbols include/hv_kernels.h declares, and the
+ctypes table mirrors the header (argument counts).  No compute calls (no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_decls():
+    src = open(os.path.join(ROOT, "include", "hv_kernels.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\bint\s+(hv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        decls[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return decls
+
+
+def test_header_matches_ctypes_table():
+    from hunyuanvideo_efficiency_amd import _lib
+    decls = _header_decls()
+    assert set(decls) == set(_lib.SIGNATURES), (set(decls) ^ set(_lib.SIGNATURES))
+    for name, n in decls.items():
+        assert len(_lib.SIGNATURES[name]) == n, name
+
+
+def test_library_loads_and_exports_every_symbol():
+    from hunyuanvideo_efficiency_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail(f"{_lib.LIB_PATH} not built: run __graft_entry__.build()")
+    lib = _lib.load()
+    for name in _header_decls():
+        assert hasattr(lib, name), name
+    assert lib.hv_abi_version() == _lib.ABI_VERSION
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from hunyuanvideo_efficiency_amd import ops, _lib
+    with pytest.raises(_lib.HVKernelError):
+        ops.ln_modulate(torch.zeros(4, 256, dtype=torch.bfloat16))
+    with pytest.raises(_lib.HVKernelError):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16))
