@@ -173,13 +173,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s) {
+                u32x4 w;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[kb][8 * s + j], c, -m_run));
-                    ls += p;
-                    pf[kb][s][j] = (__bf16)p;
+                for (int j = 0; j < 8; j += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[kb][8 * s + j], c, -m_run));
+                    const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[kb][8 * s + j + 1], c, -m_run));
+                    ls += p0 + p1;
+                    w[j >> 1] = pack_bf2(p0, p1);
                 }
+                pf[kb][s] = __builtin_bit_cast(bf16x8, w);   // (whole-vector cast: element-wise __bf16 inserts miscompile)
+            }
         l_run += ls;
         // ---------------- O^T += V^T . P^T   (4 d-blocks x 4 k-steps of 16 keys)
 #pragma unroll
@@ -193,11 +197,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
                     const char* p0 = buf + ((vread + koff) ^ (db << 6));
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * 256));
-                    bf16x8 vf;
-                    vf[0] = __builtin_bit_cast(__bf16, lo[0]); vf[1] = __builtin_bit_cast(__bf16, lo[1]);
-                    vf[2] = __builtin_bit_cast(__bf16, lo[2]); vf[3] = __builtin_bit_cast(__bf16, lo[3]);
-                    vf[4] = __builtin_bit_cast(__bf16, hi[0]); vf[5] = __builtin_bit_cast(__bf16, hi[1]);
-                    vf[6] = __builtin_bit_cast(__bf16, hi[2]); vf[7] = __builtin_bit_cast(__bf16, hi[3]);
+                    const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                     oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], oT[db], 0, 0, 0);
                 }
             }
