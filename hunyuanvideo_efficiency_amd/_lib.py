@@ -21,7 +21,8 @@ SIGNATURES = {
     "hv_ln_modulate_bf16": [_p, _p, _p, _p, _l, _i, _l, _l, _f, _i, _p],
     "hv_qknorm_rope_bf16": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _l, _l, _f, _p],
     "hv_gemm_bf16": [_p, _l, _p, _l, _p, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p, _p, _l, _p],
-    "hv_linear_smallm_bf16": [_p, _p, _p, _p, _i, _i, _i, _l, _l, _i, _p],
+    "hv_linear_smallm_bf16": [_p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _i, _p],
+    "hv_timestep_embedding_bf16": [_p, _p, _i, _i, _f, _p],
     "hv_attn_fwd_bf16": [_p, _p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _f, _p],
     "hv_patchify_f32_bf16": [_p, _p, _i, _i, _i, _i, _p],
     "hv_unpatchify_bf16": [_p, _p, _i, _i, _i, _i, _l, _p],

@@ -163,8 +163,8 @@ extern "C" int hv_qknorm_rope_bf16(void* qkv, const void* q_weight, const void* 
 // bf16 SiLU does), bit1 = SiLU on the output (applied to the bf16-rounded sum, rounded again).
 template <int MM>
 __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
-                                                    const bf16_t* __restrict__ b, bf16_t* __restrict__ out, int N, int K,
-                                                    int64_t ldx, int64_t ldo, int act) {
+                                                    const bf16_t* __restrict__ b, const bf16_t* __restrict__ addend,
+                                                    bf16_t* __restrict__ out, int N, int K, int64_t ldx, int64_t ldo, int act) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -193,22 +193,23 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x,
         if (lane == 0) {
             if (b) r += bf2f(b[n]);
             if (act & 2) r = silu_f(rbf(r));
+            if (addend) r = rbf(r) + bf2f(addend[m * ldo + n]);   // vec = vec + embedder(...) in bf16 (models.py:621,631)
             out[m * ldo + n] = f2bf(r);
         }
     }
 }
 
-extern "C" int hv_linear_smallm_bf16(const void* x, const void* W, const void* bias, void* out, int M, int N, int K,
-                                     int64_t ldx, int64_t ldo, int act, hipStream_t stream) {
+extern "C" int hv_linear_smallm_bf16(const void* x, const void* W, const void* bias, const void* addend, void* out, int M,
+                                     int N, int K, int64_t ldx, int64_t ldo, int act, hipStream_t stream) {
     if (!x || !W || !out || M < 1 || M > 4 || N < 1 || K < 8 || (K & 7) || (ldx & 7)) return HV_ERR_ARG;
     dim3 grid((N + 3) / 4), block(256);
-    const bf16_t *xp = (const bf16_t*)x, *wp = (const bf16_t*)W, *bp = (const bf16_t*)bias;
+    const bf16_t *xp = (const bf16_t*)x, *wp = (const bf16_t*)W, *bp = (const bf16_t*)bias, *ap = (const bf16_t*)addend;
     bf16_t* op = (bf16_t*)out;
     switch (M) {
-        case 1: gemv_kernel<1><<<grid, block, 0, stream>>>(xp, wp, bp, op, N, K, ldx, ldo, act); break;
-        case 2: gemv_kernel<2><<<grid, block, 0, stream>>>(xp, wp, bp, op, N, K, ldx, ldo, act); break;
-        case 3: gemv_kernel<3><<<grid, block, 0, stream>>>(xp, wp, bp, op, N, K, ldx, ldo, act); break;
-        default: gemv_kernel<4><<<grid, block, 0, stream>>>(xp, wp, bp, op, N, K, ldx, ldo, act); break;
+        case 1: gemv_kernel<1><<<grid, block, 0, stream>>>(xp, wp, bp, ap, op, N, K, ldx, ldo, act); break;
+        case 2: gemv_kernel<2><<<grid, block, 0, stream>>>(xp, wp, bp, ap, op, N, K, ldx, ldo, act); break;
+        case 3: gemv_kernel<3><<<grid, block, 0, stream>>>(xp, wp, bp, ap, op, N, K, ldx, ldo, act); break;
+        default: gemv_kernel<4><<<grid, block, 0, stream>>>(xp, wp, bp, ap, op, N, K, ldx, ldo, act); break;
     }
     return hv_check_launch();
 }
@@ -318,5 +319,25 @@ extern "C" int hv_broadcast_row_bf16(const void* src, void* dst, int64_t n_rows,
     if (n_rows == 0) return HV_OK;
     bcast_row_kernel<<<dim3((unsigned)((n_rows * D + 255) / 256)), dim3(256), 0, stream>>>((const bf16_t*)src, (bf16_t*)dst,
                                                                                           n_rows, D, ld);
+    return hv_check_launch();
+}
+
+// timestep_embedding (embed_layers.py:93-117): out[i] = cos(t*f_i), out[half+i] = sin(t*f_i), f_i = exp(-ln(P)*i/half),
+// computed in fp32 and cast to the MLP's weight dtype (bf16), embed_layers.py:153-155.  t is read from device memory.
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int n_t, int dim, float max_period) {
+    const int half = dim >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_t * half) return;
+    const int b = idx / half, i = idx % half;
+    const float f = expf(-logf(max_period) * (float)i / (float)half);
+    const float a = t[b] * f;
+    out[b * dim + i] = f2bf(cosf(a));
+    out[b * dim + half + i] = f2bf(sinf(a));
+}
+
+extern "C" int hv_timestep_embedding_bf16(const float* t, void* out, int n_t, int dim, float max_period, hipStream_t stream) {
+    if (!t || !out || n_t <= 0 || dim <= 0 || (dim & 1)) return HV_ERR_ARG;
+    const int n = n_t * (dim / 2);
+    timestep_embedding_kernel<<<dim3((n + 127) / 128), dim3(128), 0, stream>>>(t, (bf16_t*)out, n_t, dim, max_period);
     return hv_check_launch();
 }

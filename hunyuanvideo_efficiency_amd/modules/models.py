@@ -1,0 +1,318 @@
+"""Host-side mirror of hyvideo/modules/models.py (reference) for the MI355X kernels.
+
+Same class names, constructor keywords, forward signatures and state-dict key names as the
+reference (HYVideoDiffusionTransformer models.py:396-581, MMDoubleStreamBlock :21-252,
+MMSingleStreamBlock :255-393), so `load_state_dict(strict=True)` accepts reference checkpoints and
+`parallelize_transformer` can install `hybrid_seq_parallel_attn` on the blocks.  The modules only HOLD
+parameters; every forward is a fixed sequence of C-ABI kernel launches (ops.py) on preallocated
+workspaces - there is no torch arithmetic and no CPU path.
+
+Data layout in HBM (one sample, S = S_img + S_txt tokens, d = hidden):
+  x      [S, d]      bf16  residual stream; img = rows [0,S_img), txt = rows [S_img,S)  (no torch.cat)
+  xmod   [S, d]      bf16  LayerNorm+modulate output (GEMM A operand)
+  qkv    [S, 3d]     bf16  fused q|k|v rows; q,k are normalised/rotated in place; attention reads strided
+  cat    [S, d+4d]   bf16  [attn | gelu(mlp)] of the single block = A operand of linear2; the double block
+                           uses cols [0,d) for attn and cols [d,5d) as the MLP hidden buffer
+Numeric contract (production autocast-bf16 semantics): see oracle/dit_ref.py Prec(True).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .attenion import get_cu_seqlens, n_valid_text, segment_attention_
+from .token_refiner import SingleTokenRefiner
+from .layers import ParamLinear, ParamNormWeight, ModulateDiT, MLP, MLPEmbedder, TimestepEmbedder, PatchEmbed, FinalLayer
+
+BF16 = torch.bfloat16
+
+
+class _Workspace:
+    """Preallocated activation buffers for one (S_img, S_txt, d, mlp) problem size."""
+
+    def __init__(self, s_img: int, s_txt: int, d: int, mlp: int, device):
+        s = s_img + s_txt
+        self.key = (s_img, s_txt, d, mlp, str(device))
+        self.x = torch.empty(s, d, dtype=BF16, device=device)
+        self.xmod = torch.empty(s, d, dtype=BF16, device=device)
+        self.qkv = torch.empty(s, 3 * d, dtype=BF16, device=device)
+        self.cat = torch.empty(s, d + mlp, dtype=BF16, device=device)
+        self.patches = None
+        self.final = None
+
+
+class MMDoubleStreamBlock(nn.Module):
+    """Parameter holder + kernel sequence of the reference MMDoubleStreamBlock (models.py:21-252)."""
+
+    def __init__(self, hidden_size: int, heads_num: int, mlp_width_ratio: float, mlp_act_type: str = "gelu_tanh",
+                 qk_norm: bool = True, qk_norm_type: str = "rms", qkv_bias: bool = False,
+                 dtype: Optional[torch.dtype] = None, device: Optional[torch.device] = None):
+        super().__init__()
+        if mlp_act_type != "gelu_tanh" or not qk_norm or qk_norm_type != "rms":
+            raise NotImplementedError("only gelu_tanh MLP and RMS qk-norm have kernels (the shipped configuration)")
+        fk = {"device": device, "dtype": dtype}
+        self.deterministic = False
+        self.heads_num = heads_num
+        head_dim = hidden_size // heads_num
+        mlp_hidden = int(hidden_size * mlp_width_ratio)
+        for s in ("img", "txt"):
+            setattr(self, f"{s}_mod", ModulateDiT(hidden_size, 6, **fk))
+            setattr(self, f"{s}_attn_qkv", ParamLinear(hidden_size, hidden_size * 3, qkv_bias, **fk))
+            setattr(self, f"{s}_attn_q_norm", ParamNormWeight(head_dim, **fk))
+            setattr(self, f"{s}_attn_k_norm", ParamNormWeight(head_dim, **fk))
+            setattr(self, f"{s}_attn_proj", ParamLinear(hidden_size, hidden_size, qkv_bias, **fk))
+            setattr(self, f"{s}_mlp", MLP(hidden_size, mlp_hidden, **fk))
+        self.hybrid_seq_parallel_attn = None
+
+    def enable_deterministic(self):
+        self.deterministic = True
+
+    def disable_deterministic(self):
+        self.deterministic = False
+
+    def run(self, ws: _Workspace, s_img: int, s_txt: int, vec: torch.Tensor, cu1: int,
+            cos: Optional[torch.Tensor], sin: Optional[torch.Tensor]):
+        d = ws.x.shape[1]
+        H = self.heads_num
+        streams = (("img", 0, s_img, s_img if cos is not None else 0), ("txt", s_img, s_img + s_txt, 0))
+        mods = {}
+        for s, lo, hi, n_rope in streams:
+            mod = getattr(self, f"{s}_mod")
+            m = ops.linear_smallm(vec, mod.linear.weight, mod.linear.bias, silu_in=True)  # [1, 6d]
+            mods[s] = [m[0, i * d:(i + 1) * d] for i in range(6)]   # shift1, scale1, gate1, shift2, scale2, gate2
+            sh1, sc1 = mods[s][0], mods[s][1]
+            ops.ln_modulate(ws.x[lo:hi], sh1, sc1, out=ws.xmod[lo:hi])
+            qkv_l = getattr(self, f"{s}_attn_qkv")
+            ops.gemm(ws.xmod[lo:hi], qkv_l.weight, qkv_l.bias, out=ws.qkv[lo:hi])
+            ops.qknorm_rope_(ws.qkv[lo:hi], getattr(self, f"{s}_attn_q_norm").weight,
+                             getattr(self, f"{s}_attn_k_norm").weight, cos, sin, n_rope, H, d)
+        segment_attention_(self.hybrid_seq_parallel_attn, ws.qkv, ws.cat, s_img, cu1, H, d)
+        for s, lo, hi, _ in streams:
+            _, _, g1, sh2, sc2, g2 = mods[s]
+            proj, mlp = getattr(self, f"{s}_attn_proj"), getattr(self, f"{s}_mlp")
+            x = ws.x[lo:hi]
+            ops.gemm(ws.cat[lo:hi, :d], proj.weight, proj.bias, out=x, gate=g1, res=x)
+            ops.ln_modulate(x, sh2, sc2, out=ws.xmod[lo:hi])
+            hbuf = ws.cat[lo:hi, d:]
+            ops.gemm(ws.xmod[lo:hi], mlp.fc1.weight, mlp.fc1.bias, out=hbuf, act=ops.ACT_GELU_TANH)
+            ops.gemm(hbuf, mlp.fc2.weight, mlp.fc2.bias, out=x, gate=g2, res=x)
+
+    def forward(self, img, txt, vec, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
+                freqs_cis: tuple = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Reference call surface (models.py:132-142): img [1,S_img,d], txt [1,S_txt,d], vec [1,d]."""
+        assert img.shape[0] == 1, "batch 1 (cfg-distilled model, SURVEY.md top)"
+        s_img, s_txt, d = img.shape[1], txt.shape[1], img.shape[2]
+        ws = _Workspace(s_img, s_txt, d, self.img_mlp.fc1.weight.shape[0], img.device)
+        ws.x[:s_img].copy_(img[0])
+        ws.x[s_img:].copy_(txt[0])
+        cu1 = int(cu_seqlens_q[1])
+        cos, sin = freqs_cis if freqs_cis is not None else (None, None)
+        self.run(ws, s_img, s_txt, vec.to(BF16).contiguous(), cu1, cos, sin)
+        return ws.x[None, :s_img], ws.x[None, s_img:]
+
+
+class MMSingleStreamBlock(nn.Module):
+    """Parameter holder + kernel sequence of the reference MMSingleStreamBlock (models.py:255-393)."""
+
+    def __init__(self, hidden_size: int, heads_num: int, mlp_width_ratio: float = 4.0, mlp_act_type: str = "gelu_tanh",
+                 qk_norm: bool = True, qk_norm_type: str = "rms", qk_scale: float = None,
+                 dtype: Optional[torch.dtype] = None, device: Optional[torch.device] = None):
+        super().__init__()
+        if mlp_act_type != "gelu_tanh" or not qk_norm or qk_norm_type != "rms" or qk_scale is not None:
+            raise NotImplementedError("only gelu_tanh MLP, RMS qk-norm and the default scale have kernels")
+        fk = {"device": device, "dtype": dtype}
+        self.deterministic = False
+        self.hidden_size = hidden_size
+        self.heads_num = heads_num
+        head_dim = hidden_size // heads_num
+        self.mlp_hidden_dim = int(hidden_size * mlp_width_ratio)
+        self.scale = head_dim ** -0.5
+        self.linear1 = ParamLinear(hidden_size, hidden_size * 3 + self.mlp_hidden_dim, True, **fk)
+        self.linear2 = ParamLinear(hidden_size + self.mlp_hidden_dim, hidden_size, True, **fk)
+        self.q_norm = ParamNormWeight(head_dim, **fk)
+        self.k_norm = ParamNormWeight(head_dim, **fk)
+        self.modulation = ModulateDiT(hidden_size, 3, **fk)
+        self.hybrid_seq_parallel_attn = None
+
+    def enable_deterministic(self):
+        self.deterministic = True
+
+    def disable_deterministic(self):
+        self.deterministic = False
+
+    def run(self, ws: _Workspace, s_img: int, s_txt: int, vec: torch.Tensor, cu1: int,
+            cos: Optional[torch.Tensor], sin: Optional[torch.Tensor]):
+        d, H = self.hidden_size, self.heads_num
+        m = ops.linear_smallm(vec, self.modulation.linear.weight, self.modulation.linear.bias, silu_in=True)
+        shift, scale, gate = m[0, :d], m[0, d:2 * d], m[0, 2 * d:]
+        ops.ln_modulate(ws.x, shift, scale, out=ws.xmod)
+        # linear1: cols [0,3d) -> qkv ; cols [3d, 3d+mlp) -> GELU-tanh -> cat[:, d:]   (models.py:339-341,392)
+        ops.gemm(ws.xmod, self.linear1.weight, self.linear1.bias, out=ws.qkv, n_split=3 * d, out1=ws.cat[:, d:],
+                 act1=ops.ACT_GELU_TANH)
+        ops.qknorm_rope_(ws.qkv, self.q_norm.weight, self.k_norm.weight, cos, sin, s_img if cos is not None else 0, H, d)
+        segment_attention_(self.hybrid_seq_parallel_attn, ws.qkv, ws.cat, s_img, cu1, H, d)
+        ops.gemm(ws.cat, self.linear2.weight, self.linear2.bias, out=ws.x, gate=gate, res=ws.x)
+
+    def forward(self, x, vec, txt_len, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
+                freqs_cis: Tuple[torch.Tensor, torch.Tensor] = None) -> torch.Tensor:
+        """Reference call surface (models.py:326-336): x [1,S,d], vec [1,d]."""
+        assert x.shape[0] == 1
+        s, d = x.shape[1], x.shape[2]
+        ws = _Workspace(s - txt_len, txt_len, d, self.mlp_hidden_dim, x.device)
+        ws.x.copy_(x[0])
+        cos, sin = freqs_cis if freqs_cis is not None else (None, None)
+        self.run(ws, s - txt_len, txt_len, vec.to(BF16).contiguous(), int(cu_seqlens_q[1]), cos, sin)
+        return ws.x[None]
+
+
+class _Config(dict):
+    __getattr__ = dict.__getitem__
+
+
+class HYVideoDiffusionTransformer(nn.Module):
+    """HunyuanVideo transformer backbone on MI355X kernels; constructor and forward as the reference
+    (models.py:448-470,595-606).  `.config` carries the registered constructor arguments that the
+    pipeline reads (pipeline_hunyuan_video.py:927: transformer.config.in_channels)."""
+
+    def __init__(self, args: Any, patch_size: list = [1, 2, 2], in_channels: int = 4, out_channels: int = None,
+                 hidden_size: int = 3072, heads_num: int = 24, mlp_width_ratio: float = 4.0, mlp_act_type: str = "gelu_tanh",
+                 mm_double_blocks_depth: int = 20, mm_single_blocks_depth: int = 40, rope_dim_list: List[int] = [16, 56, 56],
+                 qkv_bias: bool = True, qk_norm: bool = True, qk_norm_type: str = "rms", guidance_embed: bool = False,
+                 text_projection: str = "single_refiner", use_attention_mask: bool = True,
+                 dtype: Optional[torch.dtype] = None, device: Optional[torch.device] = None):
+        super().__init__()
+        fk = {"device": device, "dtype": dtype}
+        self.config = _Config(patch_size=patch_size, in_channels=in_channels, out_channels=out_channels,
+                              hidden_size=hidden_size, heads_num=heads_num, mlp_width_ratio=mlp_width_ratio,
+                              mlp_act_type=mlp_act_type, mm_double_blocks_depth=mm_double_blocks_depth,
+                              mm_single_blocks_depth=mm_single_blocks_depth, rope_dim_list=rope_dim_list,
+                              qkv_bias=qkv_bias, qk_norm=qk_norm, qk_norm_type=qk_norm_type,
+                              guidance_embed=guidance_embed, text_projection=text_projection,
+                              use_attention_mask=use_attention_mask)
+        self.patch_size = patch_size
+        self.in_channels = in_channels
+        self.out_channels = in_channels if out_channels is None else out_channels
+        self.unpatchify_channels = self.out_channels
+        self.guidance_embed = guidance_embed
+        self.rope_dim_list = rope_dim_list
+        self.use_attention_mask = use_attention_mask
+        self.text_projection = text_projection
+        self.text_states_dim = args.text_states_dim
+        self.text_states_dim_2 = args.text_states_dim_2
+        if hidden_size % heads_num != 0:
+            raise ValueError(f"Hidden size {hidden_size} must be divisible by heads_num {heads_num}")
+        pe_dim = hidden_size // heads_num
+        if sum(rope_dim_list) != pe_dim:
+            raise ValueError(f"Got {rope_dim_list} but expected positional dim {pe_dim}")
+        if pe_dim != 128:
+            raise NotImplementedError("kernels are built for head_dim 128 (HunyuanVideo: 3072/24)")
+        if list(patch_size) != [1, 2, 2]:
+            raise NotImplementedError("kernels are built for patch_size [1,2,2]")
+        if text_projection != "single_refiner":
+            raise NotImplementedError(f"Unsupported text_projection: {text_projection}")
+        self.hidden_size = hidden_size
+        self.heads_num = heads_num
+        self.mlp_hidden = int(hidden_size * mlp_width_ratio)
+
+        self.img_in = PatchEmbed(self.patch_size, self.in_channels, self.hidden_size, **fk)
+        self.txt_in = SingleTokenRefiner(self.text_states_dim, hidden_size, heads_num, depth=2, **fk)
+        self.time_in = TimestepEmbedder(self.hidden_size, **fk)
+        self.vector_in = MLPEmbedder(self.text_states_dim_2, self.hidden_size, **fk)
+        self.guidance_in = TimestepEmbedder(self.hidden_size, **fk) if guidance_embed else None
+        self.double_blocks = nn.ModuleList([
+            MMDoubleStreamBlock(self.hidden_size, self.heads_num, mlp_width_ratio=mlp_width_ratio, mlp_act_type=mlp_act_type,
+                                qk_norm=qk_norm, qk_norm_type=qk_norm_type, qkv_bias=qkv_bias, **fk)
+            for _ in range(mm_double_blocks_depth)])
+        self.single_blocks = nn.ModuleList([
+            MMSingleStreamBlock(self.hidden_size, self.heads_num, mlp_width_ratio=mlp_width_ratio, mlp_act_type=mlp_act_type,
+                                qk_norm=qk_norm, qk_norm_type=qk_norm_type, **fk)
+            for _ in range(mm_single_blocks_depth)])
+        self.final_layer = FinalLayer(self.hidden_size, self.patch_size, self.out_channels, **fk)
+        self._ws: Optional[_Workspace] = None
+
+    @property
+    def dtype(self):
+        return self.double_blocks[0].img_attn_qkv.weight.dtype if len(self.double_blocks) else self.img_in.proj.weight.dtype
+
+    def enable_deterministic(self):
+        for b in list(self.double_blocks) + list(self.single_blocks):
+            b.enable_deterministic()
+
+    def disable_deterministic(self):
+        for b in list(self.double_blocks) + list(self.single_blocks):
+            b.disable_deterministic()
+
+    def _workspace(self, s_img: int, s_txt: int, device) -> _Workspace:
+        key = (s_img, s_txt, self.hidden_size, self.mlp_hidden, str(device))
+        if self._ws is None or self._ws.key != key:
+            self._ws = None
+            self._ws = _Workspace(s_img, s_txt, self.hidden_size, self.mlp_hidden, device)
+        return self._ws
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, text_states: torch.Tensor = None, text_mask: torch.Tensor = None,
+                text_states_2: Optional[torch.Tensor] = None, freqs_cos: Optional[torch.Tensor] = None,
+                freqs_sin: Optional[torch.Tensor] = None, guidance: torch.Tensor = None,
+                return_dict: bool = True) -> Union[torch.Tensor, Dict[str, torch.Tensor]]:
+        if x.shape[0] != 1:
+            raise NotImplementedError("batch size 1 only: the shipped model is CFG-distilled (config.py:339-341) "
+                                      "and the pipeline never doubles the batch")
+        if self.dtype != BF16:
+            raise TypeError(f"parameters must be bf16 (got {self.dtype}); build with dtype=torch.bfloat16 or call .to()")
+        dev = x.device
+        _, _, ot, oh, ow = x.shape
+        tt, th, tw = ot // self.patch_size[0], oh // self.patch_size[1], ow // self.patch_size[2]
+        s_img, s_txt, d = tt * th * tw, text_states.shape[1], self.hidden_size
+        ws = self._workspace(s_img, s_txt, dev)
+
+        # ---- modulation vector (models.py:618-631)
+        t32 = t.reshape(-1).to(torch.float32)
+        vec = self.time_in.run(t32)
+        vec = self.vector_in.run(text_states_2.to(BF16).reshape(1, -1), addend=vec)
+        if self.guidance_embed:
+            if guidance is None:
+                raise ValueError("Didn't get guidance strength for guidance distilled model.")
+            vec = self.guidance_in.run(guidance.reshape(-1).to(torch.float32), addend=vec)
+
+        # ---- embed image and text (models.py:634-642)
+        self.img_in.run(x[0].to(torch.float32).contiguous(), ws, s_img)
+        mask = text_mask if self.use_attention_mask else None
+        self.txt_in.run(text_states[0].to(BF16).contiguous(), t32, mask, out=ws.x[s_img:])
+
+        # ---- cu_seqlens (models.py:648): segment 1 = img + valid text, segment 2 = padding text
+        cu1 = s_img + (n_valid_text(text_mask) if text_mask is not None else s_txt)
+        cos = freqs_cos.to(device=dev, dtype=torch.float32).contiguous() if freqs_cos is not None else None
+        sin = freqs_sin.to(device=dev, dtype=torch.float32).contiguous() if freqs_sin is not None else None
+
+        for block in self.double_blocks:
+            block.run(ws, s_img, s_txt, vec, cu1, cos, sin)
+        for block in self.single_blocks:
+            block.run(ws, s_img, s_txt, vec, cu1, cos, sin)
+
+        img = self.final_layer.run(ws, s_img, vec)                       # [S_img, 64]
+        out = ops.unpatchify(img, self.unpatchify_channels, ot, oh, ow)  # [C,T,H,W] bf16
+        out = out[None]
+        if return_dict:
+            return {"x": out}
+        return out
+
+    def params_count(self):
+        counts = {
+            "double": sum(sum(p.numel() for p in m.parameters())
+                          for b in self.double_blocks
+                          for m in (b.img_attn_qkv, b.img_attn_proj, b.img_mlp, b.txt_attn_qkv, b.txt_attn_proj, b.txt_mlp)),
+            "single": sum(sum(p.numel() for p in m.parameters()) for b in self.single_blocks for m in (b.linear1, b.linear2)),
+            "total": sum(p.numel() for p in self.parameters()),
+        }
+        counts["attn+mlp"] = counts["double"] + counts["single"]
+        return counts
+
+
+HUNYUAN_VIDEO_CONFIG = {
+    "HYVideo-T/2": dict(mm_double_blocks_depth=20, mm_single_blocks_depth=40, rope_dim_list=[16, 56, 56],
+                        hidden_size=3072, heads_num=24, mlp_width_ratio=4),
+    "HYVideo-T/2-cfgdistill": dict(mm_double_blocks_depth=20, mm_single_blocks_depth=40, rope_dim_list=[16, 56, 56],
+                                   hidden_size=3072, heads_num=24, mlp_width_ratio=4, guidance_embed=True),
+}

@@ -109,7 +109,7 @@ def gemm(a, w, bias=None, out=None, act: int = ACT_NONE, n_split: int = 0, out1=
     return out
 
 
-def linear_smallm(x, w, bias=None, silu_in: bool = False, silu_out: bool = False, out=None):
+def linear_smallm(x, w, bias=None, silu_in: bool = False, silu_out: bool = False, out=None, addend=None):
     _chk(x, BF16, "x"), _chk(w, BF16, "w")
     m, k, ldx = _rows(x, "x")
     n, kw, ldw = _rows(w, "w")
@@ -119,7 +119,10 @@ def linear_smallm(x, w, bias=None, silu_in: bool = False, silu_out: bool = False
     _, _, ldo = _rows(out, "out")
     if bias is not None:
         _chk(bias, BF16, "bias")
-    _lib.check(_lib.load().hv_linear_smallm_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), m, n, k, ldx, ldo,
+    if addend is not None:
+        _chk(addend, BF16, "addend")
+        assert addend.shape == out.shape and addend.stride() == out.stride()
+    _lib.check(_lib.load().hv_linear_smallm_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(addend), _ptr(out), m, n, k, ldx, ldo,
                                                  (1 if silu_in else 0) | (2 if silu_out else 0), _stream()),
                "hv_linear_smallm_bf16")
     return out
@@ -184,3 +187,12 @@ def broadcast_row_(src, dst):
     _lib.check(_lib.load().hv_broadcast_row_bf16(_ptr(src), _ptr(dst), dst.shape[0], dst.shape[1], dst.stride(0), _stream()),
                "hv_broadcast_row_bf16")
     return dst
+
+
+def timestep_embedding(t_f32, dim: int = 256, max_period: float = 10000.0):
+    _chk(t_f32, torch.float32, "t")
+    t_f32 = t_f32.reshape(-1).contiguous()
+    out = torch.empty(t_f32.numel(), dim, dtype=BF16, device=t_f32.device)
+    _lib.check(_lib.load().hv_timestep_embedding_bf16(_ptr(t_f32), _ptr(out), t_f32.numel(), dim, max_period, _stream()),
+               "hv_timestep_embedding_bf16")
+    return out

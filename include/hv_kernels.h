@@ -56,9 +56,15 @@ int hv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const v
 
 /* K9/K11: small-M Linear (M <= 4): out = act_out(W . act_in(x) + b).  act bit0: SiLU on input
  * (ModulateDiT / adaLN: Linear(SiLU(vec)), modulate_layers.py:27-28), bit1: SiLU on output
- * (MLPEmbedder / TimestepEmbedder hidden layer, mlp_layers.py:72-73, embed_layers.py:140-150). */
-int hv_linear_smallm_bf16(const void* x, const void* W, const void* bias, void* out, int M, int N, int K,
-                          int64_t ldx, int64_t ldo, int act, hipStream_t stream);
+ * (MLPEmbedder / TimestepEmbedder hidden layer, mlp_layers.py:72-73, embed_layers.py:140-150).
+ * addend (nullable, same layout as out): out = bf16(y) + addend, the bf16 `vec = vec + embedder(...)` adds of
+ * models.py:621,631 and token_refiner.py:229. */
+int hv_linear_smallm_bf16(const void* x, const void* W, const void* bias, const void* addend, void* out, int M,
+                          int N, int K, int64_t ldx, int64_t ldo, int act, hipStream_t stream);
+
+/* timestep_embedding (modules/embed_layers.py:93-117,152-155): [cos(t f_i) | sin(t f_i)] in fp32 -> bf16;
+ * t: n_t device floats. */
+int hv_timestep_embedding_bf16(const float* t, void* out, int n_t, int dim, float max_period, hipStream_t stream);
 
 /* K6/K6': softmax(scale * q k^T) v, bf16, head_dim 128, non-causal, over ONE contiguous key segment
  * (flash_attn_varlen_func / _flash_attn_forward of modules/attenion.py:107-120,181-207: the caller

@@ -1,0 +1,107 @@
+"""GPU parity of the host mirror (hunyuanvideo_efficiency_amd.modules) against the oracle and the golden
+fixtures generated from the reference: BASELINE.json configs[0] (tiny DiT, d=256, 1+1 blocks, 16x16x5 latent)."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hunyuanvideo_efficiency_amd import synthetic as syn  # noqa: E402
+from oracle import dit_ref as R  # noqa: E402
+
+DEV = "cuda:0"
+E = R.Prec(True)
+
+
+def rel(a, b):
+    return float((a.float().cpu() - b.float().cpu()).abs().max() / b.float().abs().max())
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from hunyuanvideo_efficiency_amd.selftest import build_model
+    cfg = syn.tiny_config()
+    return cfg, build_model(cfg, DEV)
+
+
+def test_tiny_step_vs_oracle():
+    from hunyuanvideo_efficiency_amd.selftest import tiny_step_vs_oracle
+    assert tiny_step_vs_oracle(DEV) < 3e-2
+
+
+def test_tiny_forward_vs_reference_golden(tiny, golden):
+    """Output of the GPU bf16 path vs the fp32 output of the IMPORTED REFERENCE (fixture dit_tiny_forward):
+    bounded by bf16 rounding drift (3e-2 of the output range; the oracle's own bf16 emulation sits at the
+    same distance, tests/test_oracle_golden.py::test_bf16_emulation_stays_near_fp32)."""
+    cfg, model = tiny
+    g = golden("dit_tiny_forward")
+    from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
+    T, H, W = g["latent_thw"].tolist()
+    cos, sin = get_nd_rotary_pos_embed(cfg.rope_dim_list, [T, H // 2, W // 2], theta=256, use_real=True, device=DEV)
+    with torch.no_grad():
+        out = model(g["x"].to(DEV), g["t"].to(DEV), text_states=g["text_states"].to(DEV), text_mask=g["text_mask"].to(DEV),
+                    text_states_2=g["text_states_2"].to(DEV), freqs_cos=cos, freqs_sin=sin, guidance=g["guidance"].to(DEV),
+                    return_dict=True)["x"]
+    assert out.shape == g["out"].shape and out.dtype == torch.bfloat16
+    assert rel(out, g["out"]) < 3e-2
+
+
+def test_block_call_surfaces_vs_oracle(tiny, golden):
+    """MMDoubleStreamBlock / MMSingleStreamBlock through their reference forward signatures (models.py:132-142,
+    326-336) on the fixture inputs, vs the oracle in the bf16-emulated contract (tight) and vs the reference's fp32
+    outputs (drift bound)."""
+    cfg, model = tiny
+    g = golden("dit_blocks")
+    sd = {k: p.float().cpu() for k, p in model.state_dict().items()}
+    cos, sin = R.rope_tables([5, 8, 8], cfg.rope_dim_list, 256.0)
+    img, txt, vec = E.r(g["img"]), E.r(g["txt"]), E.r(g["vec"])
+    cu = g["cu"]
+    bf = lambda t: t.to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        io, to = model.double_blocks[0](bf(img), bf(txt), bf(vec), cu, cu, 352, 352, (cos.to(DEV), sin.to(DEV)))
+        so = model.single_blocks[0](bf(torch.cat([img, txt], 1)), bf(vec), txt.shape[1], cu, cu, 352, 352,
+                                    (cos.to(DEV), sin.to(DEV)))
+    rio, rto = R.double_block(sd, "double_blocks.0.", img, txt, vec, cu, cos, sin, cfg.heads_num, E)
+    rso = R.single_block(sd, "single_blocks.0.", torch.cat([img, txt], 1), vec, txt.shape[1], cu, cos, sin, cfg.heads_num, E)
+    for got, ref in ((io, rio), (to, rto), (so, rso)):
+        torch.testing.assert_close(got.float().cpu(), ref, rtol=2 ** -6, atol=6e-2)   # 2 bf16 ulps of |x| <= ~6
+    assert rel(io, g["img_out"]) < 2e-2 and rel(to, g["txt_out"]) < 2e-2 and rel(so, g["single_out"]) < 2e-2
+
+
+def test_scheduler_surface(golden):
+    from hunyuanvideo_efficiency_amd.diffusion.schedulers import FlowMatchDiscreteScheduler
+    g = golden("dit_scheduler")
+    for n in (30, 50):
+        s = FlowMatchDiscreteScheduler(shift=7.0, reverse=True, solver="euler")
+        s.set_timesteps(n, device=DEV, n_tokens=99)
+        torch.testing.assert_close(s.sigmas, g[f"sigmas{n}"], rtol=0, atol=1e-7)
+        torch.testing.assert_close(s.timesteps.cpu(), g[f"timesteps{n}"], rtol=0, atol=1e-4)
+    s = FlowMatchDiscreteScheduler(shift=7.0, reverse=True, solver="euler")
+    s.set_timesteps(50, device=DEV)
+    cur = g["traj"][0].to(DEV).to(torch.float16)
+    for i in range(3):
+        cur = s.step(g[f"v{i}"].to(DEV).to(torch.bfloat16), s.timesteps[i], cur, return_dict=False)[0]
+        assert cur.dtype == torch.float32
+        torch.testing.assert_close(cur.cpu(), g["traj"][i + 1], rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        s.step(g["v0"].to(DEV), 3, cur)
+
+
+def test_attention_surface_flash_and_torch_modes():
+    """attention() with the reference's signature: mode="flash" honours cu_seqlens, mode="torch" ignores them
+    (what tests/test_attention.py of the reference uses as its baseline)."""
+    from hunyuanvideo_efficiency_amd.modules.attenion import attention, get_cu_seqlens
+    H, S = 2, 352
+    q, k, v = (E.r(syn.hashed_uniform((1, S, H, 128), f"as.{n}", 3) * 1.7) for n in "qkv")
+    mask = torch.zeros(1, 32, dtype=torch.int64)
+    mask[0, :11] = 1
+    cu = get_cu_seqlens(mask.to(DEV), 320)
+    assert cu.tolist() == [0, 331, 352] and cu.dtype == torch.int32
+    d = lambda t: t.to(DEV).to(torch.bfloat16)
+    out = attention(d(q), d(k), d(v), mode="flash", cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=S, max_seqlen_kv=S)
+    ref = R.attention_varlen(q, k, v, cu.cpu(), E)
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=2 ** -7, atol=8e-3)
+    out = attention(d(q), d(k), d(v), mode="torch")
+    ref = R.sdpa(q, k, v, E).reshape(1, S, H * 128)
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=2 ** -7, atol=8e-3)
