@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the HunyuanVideo denoise hot path on MI355X (BASELINE.json metric).
+
+One "step" = one full denoise step: HYVideoDiffusionTransformer.forward (20 double + 40 single blocks,
+d=3072, 24 heads) + FlowMatchDiscreteScheduler.step on synthetic inputs already resident in HBM,
+random-init (deterministic hash) bf16 weights.  Workload at N=1: 720x1280x129f (latent 16x33x90x160,
+S = 118,800 image + 256 text tokens), the configuration BASELINE.json's metric is quoted on.
+N>1: the same single video sharded over the token axis (Ulysses sequence parallelism over RCCL all-to-all),
+i.e. strong scaling; `value` is whole-job denoise-steps/s.
+
+Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` (dominant kernel = flash
+attention, MFMA-bound, measured with HIP events on the launch stream inside the timed region) and
+`cpu_baseline` (the oracle, i.e. the CPU restatement of the reference path, timed on this box's host cores on
+a bounded sample and FLOP-scaled - a reported baseline, not a target).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (latent T, H, W)
+    "720p129f": (33, 90, 160),
+    "544p65f": (17, 68, 120),
+    "tiny": (5, 16, 16),
+}
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def step_flops(s_img, s_txt, d=3072, n_double=20, n_single=40):
+    s = s_img + s_txt
+    return (n_double + n_single) * (24 * d * d * s + 4 * s * s * d) + 256 * s_img * d
+
+
+def cpu_baseline(f_step, seconds_budget=30.0):
+    """Oracle (CPU port of the reference path, fp32 eager) on one double + one single block at full width
+    d=3072, S=1024+256 tokens; extrapolated to a full step by algorithmic FLOPs (stated as such)."""
+    import torch
+    from hunyuanvideo_efficiency_amd import synthetic as syn
+    from oracle import dit_ref as R
+    cfg = syn.DiTConfig(mm_double_blocks_depth=1, mm_single_blocks_depth=1)
+    d, s_img, s_txt = cfg.hidden_size, 1024, 256
+    gen_dev = "cuda" if torch.cuda.is_available() else "cpu"
+    sd = {}
+    for k, shp in syn.dit_param_shapes(cfg).items():
+        if k.startswith("double_blocks.0.") or k.startswith("single_blocks.0."):
+            sd[k] = syn.synth_param(k, shp, 0, gen_dev).cpu()
+    img = syn.hashed_uniform((1, s_img, d), "cpu.img", 0) * 1.7
+    txt = syn.hashed_uniform((1, s_txt, d), "cpu.txt", 0) * 1.7
+    vec = syn.hashed_uniform((1, d), "cpu.vec", 0) * 0.5
+    cos, sin = R.rope_tables([4, 16, 16], cfg.rope_dim_list, 256.0)
+    cu = torch.tensor([0, s_img + 11, s_img + s_txt], dtype=torch.int32)
+    cores = torch.get_num_threads()
+    f_sample = 2 * (24 * d * d * (s_img + s_txt) + 4 * (s_img + s_txt) ** 2 * d)
+    reps, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while True:
+            io, to = R.double_block(sd, "double_blocks.0.", img, txt, vec, cu, cos, sin, cfg.heads_num, R.FP32)
+            R.single_block(sd, "single_blocks.0.", torch.cat([io, to], 1), vec, s_txt, cu, cos, sin, cfg.heads_num, R.FP32)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > seconds_budget * 0.5 or reps >= 8:
+                break
+    sec_per_sample = el / reps
+    cpu_flops = f_sample / sec_per_sample
+    return {"value": cpu_flops / f_step, "unit": "denoise-steps/s (FLOP-scaled extrapolation from the sample)",
+            "cores": cores, "kind": "port",
+            "sample": f"oracle fp32: 1 double + 1 single block, d=3072, S={s_img}+{s_txt}, {reps} reps, "
+                      f"{sec_per_sample:.2f} s each = {cpu_flops / 1e12:.3f} TFLOP/s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="720p129f", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from hunyuanvideo_efficiency_amd import _lib, ops, synthetic as syn
+    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.diffusion.schedulers import FlowMatchDiscreteScheduler
+    from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
+    _lib.load()
+
+    tiny = a.workload == "tiny"
+    cfg = syn.tiny_config() if tiny else syn.DiTConfig()
+    T, H, W = WORKLOADS[a.workload]
+    s_img, s_txt = T * (H // 2) * (W // 2), 256
+    model = build_model(cfg, dev, seed=0)
+    if world > 1:
+        from hunyuanvideo_efficiency_amd.inference import parallelize_transformer_module
+        parallelize_transformer_module(model, dist.group.WORLD)
+    x, ts, tm, ts2 = syn.synth_dit_inputs(cfg, (T, H, W), s_txt, 11, seed=42, device=dev)
+    ts = ts.to(torch.bfloat16)
+    cos, sin = get_nd_rotary_pos_embed(cfg.rope_dim_list, [T, H // 2, W // 2], theta=256, use_real=True, device=dev)
+    guidance = (torch.tensor([6.0], dtype=torch.float32, device=dev).to(torch.bfloat16) * 1000.0)
+    n_total = a.warmup + a.steps
+    sched = FlowMatchDiscreteScheduler(shift=7.0, reverse=True, solver="euler")
+    sched.set_timesteps(max(n_total, 50), device=dev)
+    lat = x.clone()
+
+    def one_step(i, lat):
+        t = sched.timesteps[i]
+        v = model(lat, t.repeat(1), text_states=ts, text_mask=tm, text_states_2=ts2, freqs_cos=cos, freqs_sin=sin,
+                  guidance=guidance, return_dict=True)["x"]
+        return sched.step(v, t, lat, return_dict=False)[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(a.warmup):
+            lat = one_step(i, lat)
+        barrier()
+        ops.PROFILE_ATTN = []          # HIP events around every main-segment attention launch, on the launch stream
+        t0 = time.perf_counter()
+        for i in range(a.warmup, n_total):
+            lat = one_step(i, lat)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    assert bool(torch.isfinite(lat).all()), "non-finite latents"
+
+    # dominant kernel: flash attention (main segment launches only: n_kv > 1024)
+    att_ms, att_flop = [], []
+    for e0, e1, nq, nkv, nh in prof:
+        if nkv > 1024 or tiny:
+            att_ms.append(e0.elapsed_time(e1))
+            att_flop.append(4.0 * nq * nkv * 128 * nh)
+    if rank == 0:
+        f_step = step_flops(s_img, s_txt, cfg.hidden_size, cfg.mm_double_blocks_depth, cfg.mm_single_blocks_depth)
+        ms_per_step = elapsed / a.steps * 1e3
+        avg_ms = sum(att_ms) / max(len(att_ms), 1)
+        avg_flop = sum(att_flop) / max(len(att_flop), 1)
+        achieved = avg_flop / (avg_ms * 1e-3) / 1e12 if att_ms else 0.0
+        out = {
+            "metric": "denoise-steps/sec (720x1280x129f, HunyuanVideo DiT 20+40 blocks, bf16)" if not tiny else "denoise-steps/sec (tiny)",
+            "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (hash-generated latents/text embeddings, random-init weights)",
+            "config": {"workload": f"{a.workload}: latent 16x{T}x{H}x{W}, S_img={s_img}, S_txt={s_txt} (11 valid), "
+                                   f"d={cfg.hidden_size}, heads={cfg.heads_num}, {cfg.mm_double_blocks_depth}+{cfg.mm_single_blocks_depth} blocks",
+                       "parallelism": "single GPU" if world == 1 else f"ulysses{world} (token-axis shard, RCCL all-to-all)"},
+            "sec_per_video_50steps_denoise_only": 50 * ms_per_step / 1e3,
+            "step_pflop": f_step / 1e15,
+            "step_mfma_frac": f_step / (ms_per_step * 1e-3) / (world * PEAK_BF16_TFLOPS * 1e12),
+            "roofline": {"kernel": "attn_fwd_kernel (hv_attn_fwd_bf16, main segment)", "bound": "mfma",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "launches": len(att_ms), "avg_launch_ms": avg_ms, "flop_per_launch": avg_flop},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(f_step)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@ from . import _lib
 
 BF16 = torch.bfloat16
 ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
+PROFILE_ATTN = None  # set to a list by bench.py to collect (start_event, end_event, n_q, n_kv, heads) per launch
 
 
 def _stream() -> int:
@@ -137,8 +138,15 @@ def attn_fwd(q, k, v, out, n_heads: int, scale: Optional[float] = None):
     assert v.shape[0] == n_kv and out.shape[0] == n_q
     if scale is None:
         scale = 128 ** -0.5
+    prof = PROFILE_ATTN
+    if prof is not None:   # bench.py: HIP events on the launch stream around the dominant kernel
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.load().hv_attn_fwd_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), q.stride(0), k.stride(0), v.stride(0),
                                             out.stride(0), n_q, n_kv, n_heads, 128, scale, _stream()), "hv_attn_fwd_bf16")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, n_q, n_kv, n_heads))
     return out
 
 
