@@ -29,6 +29,7 @@ SIGNATURES = {
     "hv_euler_step_f32": [_p, _p, _f, _l, _p],
     "hv_masked_mean_bf16": [_p, _p, _p, _i, _i, _p],
     "hv_broadcast_row_bf16": [_p, _p, _l, _i, _l, _p],
+    "hv_copy3d_bf16": [_p, _p, _i, _l, _i, _l, _l, _l, _l, _p],
 }
 
 

@@ -341,3 +341,31 @@ extern "C" int hv_timestep_embedding_bf16(const float* t, void* out, int n_t, in
     timestep_embedding_kernel<<<dim3((n + 127) / 128), dim3(128), 0, stream>>>(t, (bf16_t*)out, n_t, dim, max_period);
     return hv_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Batched strided 2-D copy (the pack / unpack steps of the Ulysses head<->token exchange, C1):
+//   dst[b*dst_bs + r*dst_ld + c] = src[b*src_bs + r*src_ld + c],  c < cols (cols % 8 == 0), 16 B per lane.
+__global__ __launch_bounds__(256) void copy3d_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows,
+                                                      int cvec, int64_t src_bs, int64_t src_ld, int64_t dst_bs, int64_t dst_ld) {
+    const int b = blockIdx.z;
+    const int64_t total = (int64_t)rows * cvec;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cvec;
+        const int c = (int)(i % cvec) * 8;
+        *reinterpret_cast<u32x4*>(dst + b * dst_bs + r * dst_ld + c) =
+            *reinterpret_cast<const u32x4*>(src + b * src_bs + r * src_ld + c);
+    }
+}
+
+extern "C" int hv_copy3d_bf16(const void* src, void* dst, int n_batch, int64_t rows, int cols, int64_t src_batch_stride,
+                              int64_t src_ld, int64_t dst_batch_stride, int64_t dst_ld, hipStream_t stream) {
+    if (!src || !dst || n_batch < 0 || rows < 0 || cols <= 0 || (cols & 7) || (src_ld & 7) || (dst_ld & 7) ||
+        (src_batch_stride & 7) || (dst_batch_stride & 7) || rows > 0x7fffffff)
+        return HV_ERR_ARG;
+    if (n_batch == 0 || rows == 0) return HV_OK;
+    const int64_t total = rows * (cols / 8);
+    const unsigned gx = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    copy3d_kernel<<<dim3(gx, 1, (unsigned)n_batch), dim3(256), 0, stream>>>((const bf16_t*)src, (bf16_t*)dst, (int)rows, cols / 8,
+                                                                            src_batch_stride, src_ld, dst_batch_stride, dst_ld);
+    return hv_check_launch();
+}

@@ -1,0 +1,140 @@
+"""Ulysses sequence-parallel attention over RCCL/xGMI - the object the reference installs on every block as
+`hybrid_seq_parallel_attn` (xfuser.core.long_ctx_attention.xFuserLongContextAttention, a third-party class reached
+from hyvideo/inference.py:80-83 and called at hyvideo/modules/attenion.py:169-180 and tests/test_attention.py:90-102).
+
+Semantics (pinned by the reference's tests/test_attention.py:107-109: output == unsharded attention over img|txt):
+every rank holds S_loc image tokens x all H heads plus the (replicated) joint text tokens.  One all-to-all per
+tensor turns "my tokens, all heads" into "all tokens, my H/P heads"; flash attention runs over the full sequence
+for those heads with the joint tokens appended at the rear; the inverse all-to-all returns each token's output to
+its owner and a tiny all-gather returns the text rows of every head group.
+
+MI355X mapping: the 8 GPUs form a full xGMI mesh, so all-to-all is the mesh-native collective (each pair has its own
+link); messages are S_loc x (H/P*128) bf16 = 11.4 MB per peer at 720p/P=8, large enough to run at link rate.  The
+exchange is `torch.distributed.all_to_all_single` on the "nccl" (= RCCL) backend; the token<->head re-layout on each
+side is one HBM-bound strided-copy kernel (hv_copy3d_bf16) and the attention is hv_attn_fwd_bf16 reading the
+received buffers in place (no concatenation)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+BF16 = torch.bfloat16
+
+
+class _HipKernels:
+    """The product's kernel set (C ABI).  tests/ substitutes a CPU double to exercise the exchange logic under gloo."""
+
+    @staticmethod
+    def copy3d(src, dst, n_batch, rows, cols, src_bs, src_ld, dst_bs, dst_ld):
+        from . import ops
+        return ops.copy3d(src, dst, n_batch, rows, cols, src_bs, src_ld, dst_bs, dst_ld)
+
+    @staticmethod
+    def attn_fwd(q, k, v, out, heads):
+        from . import ops
+        return ops.attn_fwd(q, k, v, out, heads)
+
+
+class UlyssesLongContextAttention:
+    """Constructible with no arguments like xFuserLongContextAttention(); uses the default (WORLD) group unless a
+    sequence-parallel group was registered with set_sequence_parallel_group()."""
+
+    _default_group = None
+
+    def __init__(self, group=None, kernels=None):
+        self.group = group if group is not None else UlyssesLongContextAttention._default_group
+        self.k = kernels or _HipKernels
+        self._bufs = {}
+
+    @classmethod
+    def set_sequence_parallel_group(cls, group):
+        cls._default_group = group
+
+    # ------------------------------------------------------------------ helpers
+    def _world(self):
+        return dist.get_world_size(self.group), dist.get_rank(self.group)
+
+    def _buf(self, name, shape, device):
+        b = self._bufs.get(name)
+        if b is None or tuple(b.shape) != tuple(shape) or b.device != device:
+            b = torch.empty(*shape, dtype=BF16, device=device)
+            self._bufs[name] = b
+        return b
+
+    def _core(self, q_src, k_src, v_src, ld_src, jq, jk, jv, ld_j, s_loc, n_j, heads, out, ld_out):
+        """q_src/k_src/v_src: tensors whose data_ptr is (row 0, head 0) of the local image rows, row stride ld_src;
+        jq/jk/jv: same for the n_j joint (text) rows, row stride ld_j; out: destination [s_loc + n_j rows, heads*128]
+        with row stride ld_out."""
+        P, rank = self._world()
+        if heads % P != 0:
+            raise ValueError(f"Ulysses degree {P} must divide the head count {heads} (hybrid ring attention is not built)")
+        hp = heads // P
+        w = hp * 128
+        dev = q_src.device
+        s_img = P * s_loc
+        n_tot = s_img + n_j
+        full = {n: self._buf(n, (n_tot, w), dev) for n in ("qf", "kf", "vf", "of")}
+        send = self._buf("send", (P * s_loc, w), dev)
+        for name, src, j in (("qf", q_src, jq), ("kf", k_src, jk), ("vf", v_src, jv)):
+            # pack: send[p][r][:] = src[r][p*w : (p+1)*w]
+            self.k.copy3d(src, send, P, s_loc, w, w, ld_src, s_loc * w, w)
+            dist.all_to_all_single(full[name][:s_img], send, group=self.group)
+            if n_j:
+                # joint rows at the rear, my head group only: full[s_img + r][:] = j[r][rank*w : (rank+1)*w]
+                self.k.copy3d(j[:, rank * w:], full[name][s_img:], 1, n_j, w, 0, ld_j, 0, w)
+        self.k.attn_fwd(full["qf"], full["kf"], full["vf"], full["of"], hp)
+        recv = self._buf("recv", (P * s_loc, w), dev)
+        dist.all_to_all_single(recv, full["of"][:s_img], group=self.group)
+        # unpack: out[r][p*w + c] = recv[p][r][c]
+        self.k.copy3d(recv, out, P, s_loc, w, s_loc * w, w, w, ld_out)
+        if n_j:
+            recv_t = self._buf("recv_t", (P * n_j, w), dev)
+            dist.all_gather_into_tensor(recv_t, full["of"][s_img:].contiguous(), group=self.group)
+            self.k.copy3d(recv_t, out[s_loc:], P, n_j, w, n_j * w, w, w, ld_out)
+
+    # ------------------------------------------------------------------ reference hook signature
+    def __call__(self, attn, query, key, value, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+                 alibi_slopes=None, deterministic=False, return_attn_probs=False, joint_tensor_query=None,
+                 joint_tensor_key=None, joint_tensor_value=None, joint_strategy="none"):
+        """query/key/value: [1, S_loc, H, D]; joint_*: [1, n_j, H, D] replicated on every rank -> [1, S_loc + n_j, H, D]."""
+        if dropout_p != 0.0 or causal or softmax_scale is not None:
+            raise NotImplementedError("inference path: dropout 0, non-causal, default 1/sqrt(D) scale")
+        has_joint = joint_tensor_query is not None
+        if has_joint and joint_strategy != "rear":
+            raise NotImplementedError('joint tensors are appended at the rear (joint_strategy="rear")')
+        b, s_loc, h, d = query.shape
+        if b != 1 or d != 128:
+            raise NotImplementedError("batch 1, head_dim 128")
+        q2, k2, v2 = (_flat(t) for t in (query, key, value))
+        n_j = joint_tensor_query.shape[1] if has_joint else 0
+        out = torch.empty(1, s_loc + n_j, h, d, dtype=BF16, device=query.device)
+        if has_joint and n_j:
+            jq, jk, jv = (_flat(t) for t in (joint_tensor_query, joint_tensor_key, joint_tensor_value))
+            ld_j = jq.stride(0)
+        else:
+            jq = jk = jv = None
+            ld_j = 0
+        assert q2.stride(0) == k2.stride(0) == v2.stride(0)
+        self._core(q2, k2, v2, q2.stride(0), jq, jk, jv, ld_j, s_loc, n_j, h, out.view(s_loc + n_j, h * d), h * d)
+        return out
+
+    # ------------------------------------------------------------------ block-internal fast path
+    def run_fused(self, qkv: torch.Tensor, cat: torch.Tensor, s_img_loc: int, cu1: int, heads: int, d: int):
+        """q|k|v live in the fused rows of `qkv` [S_loc_total, 3d]; rows [0, s_img_loc) are local image tokens, rows
+        [s_img_loc, cu1) the valid text tokens (joint); output goes to cat[:cu1, :d]."""
+        n_j = cu1 - s_img_loc
+        ld = qkv.stride(0)
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        self._core(q, k, v, ld, q[s_img_loc:], k[s_img_loc:], v[s_img_loc:], ld, s_img_loc, n_j, heads, cat, cat.stride(0))
+
+
+def _flat(t: torch.Tensor) -> torch.Tensor:
+    """[1,S,H,D] -> [S, H*D] view (heads packed inside the token row)."""
+    assert t.dim() == 4 and t.shape[0] == 1 and t.stride(3) == 1 and t.stride(2) == t.shape[3]
+    return t.as_strided((t.shape[1], t.shape[2] * t.shape[3]), (t.stride(1), 1), t.storage_offset())
+
+
+# name used by the reference's import site (inference.py:80: `from xfuser.core.long_ctx_attention import ...`)
+xFuserLongContextAttention = UlyssesLongContextAttention

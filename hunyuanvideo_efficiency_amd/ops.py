@@ -204,3 +204,12 @@ def timestep_embedding(t_f32, dim: int = 256, max_period: float = 10000.0):
     _lib.check(_lib.load().hv_timestep_embedding_bf16(_ptr(t_f32), _ptr(out), t_f32.numel(), dim, max_period, _stream()),
                "hv_timestep_embedding_bf16")
     return out
+
+
+def copy3d(src, dst, n_batch: int, rows: int, cols: int, src_bs: int, src_ld: int, dst_bs: int, dst_ld: int):
+    """dst[b][r][:cols] = src[b][r][:cols] with explicit element strides; src/dst are any bf16 GPU tensors whose
+    data_ptr() is element (0,0,0) of the region."""
+    _chk(src, BF16, "src", False), _chk(dst, BF16, "dst", False)
+    _lib.check(_lib.load().hv_copy3d_bf16(_ptr(src), _ptr(dst), n_batch, rows, cols, src_bs, src_ld, dst_bs, dst_ld,
+                                          _stream()), "hv_copy3d_bf16")
+    return dst

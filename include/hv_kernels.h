@@ -90,6 +90,12 @@ int hv_masked_mean_bf16(const void* x, const int* mask, void* out, int L, int D,
 /* token_refiner.py:155-157: fully masked query rows see only key 0 -> their attention output is v[0]. */
 int hv_broadcast_row_bf16(const void* src, void* dst, int64_t n_rows, int D, int64_t ld, hipStream_t stream);
 
+/* C1 pack/unpack: batched strided 2-D copy dst[b][r][c] = src[b][r][c] with independent batch/row strides
+ * (elements).  Re-lays tokens x heads for the Ulysses all-to-all (xfuser SeqAllToAll4D reached from
+ * modules/attenion.py:169-180); the exchange itself is RCCL (torch.distributed "nccl"). cols % 8 == 0. */
+int hv_copy3d_bf16(const void* src, void* dst, int n_batch, int64_t rows, int cols, int64_t src_batch_stride,
+                   int64_t src_ld, int64_t dst_batch_stride, int64_t dst_ld, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,37 @@ def test_attention_surface_flash_and_torch_modes():
     out = attention(d(q), d(k), d(v), mode="torch")
     ref = R.sdpa(q, k, v, E).reshape(1, S, H * 128)
     torch.testing.assert_close(out.float().cpu(), ref, rtol=2 ** -7, atol=8e-3)
+
+
+def test_sequence_parallel_path_single_rank_rccl(tiny, golden):
+    """The SP code path on the GPU with a 1-rank RCCL group: hv_copy3d pack/unpack + all_to_all_single +
+    head-sharded attention buffers must reproduce the non-SP forward bit for bit (P=1 exchanges are identities).
+    Multi-rank indexing is covered on CPU by tests/test_ulysses_gloo.py; the 8-GPU run is the driver's."""
+    import os
+    import torch.distributed as dist
+    from hunyuanvideo_efficiency_amd.inference import parallelize_transformer_module
+    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
+    cfg, model = tiny
+    g = golden("dit_tiny_forward")
+    T, H, W = g["latent_thw"].tolist()
+    cos, sin = get_nd_rotary_pos_embed(cfg.rope_dim_list, [T, H // 2, W // 2], theta=256, use_real=True, device=DEV)
+    kw = dict(text_states=g["text_states"].to(DEV), text_mask=g["text_mask"].to(DEV), text_states_2=g["text_states_2"].to(DEV),
+              freqs_cos=cos, freqs_sin=sin, guidance=g["guidance"].to(DEV), return_dict=True)
+    with torch.no_grad():
+        base = model(g["x"].to(DEV), g["t"].to(DEV), **kw)["x"].clone()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        sp_model = build_model(cfg, DEV)
+        parallelize_transformer_module(sp_model, None)
+        with torch.no_grad():
+            out = sp_model(g["x"].to(DEV), g["t"].to(DEV), **kw)["x"]
+        torch.cuda.synchronize()
+        assert torch.equal(out, base)
+    finally:
+        if created:
+            dist.destroy_process_group()
