@@ -170,3 +170,61 @@ def synth_dit_inputs(cfg: DiTConfig, latent_thw, txt_len: int = 256, n_valid_txt
     text_mask = torch.zeros(1, txt_len, dtype=torch.int64, device=device)
     text_mask[:, :n_valid_txt] = 1
     return x, text_states, text_mask, text_states_2
+
+
+# ------------------------------------------------------------------------------------------------ VAE decoder
+VAE_BLOCK_OUT_CHANNELS = (128, 256, 512, 512)   # shipped 884-16c-hy VAE
+
+
+def vae_decoder_param_shapes(block_out_channels=VAE_BLOCK_OUT_CHANNELS, latent_channels: int = 16, out_channels: int = 3,
+                             layers_per_block: int = 2) -> Dict[str, Tuple[int, ...]]:
+    """State-dict layout of AutoencoderKLCausal3D's decode side (vae/autoencoder_kl_causal_3d.py:98-115,
+    vae/vae.py:158-226, vae/unet_causal_3d_blocks.py:320-347,579-616,822-851); checked against the imported reference
+    by tools/make_golden_vae.py (load_state_dict strict)."""
+    t: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(name, co, ci, k):
+        t[name + ".weight"] = (co, ci, k, k, k)
+        t[name + ".bias"] = (co,)
+
+    def norm(name, c):
+        t[name + ".weight"] = (c,)
+        t[name + ".bias"] = (c,)
+
+    def resnet(pre, ci, co):
+        norm(pre + "norm1", ci)
+        conv(pre + "conv1.conv", co, ci, 3)
+        norm(pre + "norm2", co)
+        conv(pre + "conv2.conv", co, co, 3)
+        if ci != co:
+            conv(pre + "conv_shortcut.conv", co, ci, 1)
+
+    conv("post_quant_conv", latent_channels, latent_channels, 1)
+    top = block_out_channels[-1]
+    conv("decoder.conv_in.conv", top, latent_channels, 3)
+    resnet("decoder.mid_block.resnets.0.", top, top)
+    a = "decoder.mid_block.attentions.0."
+    norm(a + "group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        t[a + n + ".weight"] = (top, top)
+        t[a + n + ".bias"] = (top,)
+    resnet("decoder.mid_block.resnets.1.", top, top)
+    rev = list(reversed(block_out_channels))
+    prev = rev[0]
+    nb = len(block_out_channels)
+    for i, oc in enumerate(rev):
+        for j in range(layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}.", prev if j == 0 else oc, oc)
+        spatial = i < 3
+        temporal = (i >= nb - 1 - 2) and (i != nb - 1)
+        if spatial or temporal:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv.conv", oc, oc, 3)
+        prev = oc
+    norm("decoder.conv_norm_out", block_out_channels[0])
+    conv("decoder.conv_out.conv", out_channels, block_out_channels[0], 3)
+    return t
+
+
+def synth_vae_state_dict(block_out_channels=VAE_BLOCK_OUT_CHANNELS, seed: int = 0, device="cpu", dtype=torch.float32):
+    return {k: synth_param("vae." + k, shp, seed, device).to(dtype)
+            for k, shp in vae_decoder_param_shapes(block_out_channels).items()}
