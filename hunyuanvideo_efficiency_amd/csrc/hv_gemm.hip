@@ -1,15 +1,21 @@
-// bf16 MFMA GEMM with fused epilogues for the DiT linears (K2, K7, K8, K10, K14-dequantised):
-//     C[M,N] = A[M,K] . W[N,K]^T (+ bias[N])  ->  activation / gated residual / column split
+// MFMA GEMM with fused epilogues for the DiT linears (K2, K7, K8, K10, K14-dequantised) and - through the same
+// main loop with a gathering A-operand - the VAE's CausalConv3d as an implicit GEMM (K15 + K17):
+//     C[M,N] = A[M,K] . W[N,K]^T (+ bias[N])  ->  activation / gated residual / column split / fp32 out
 // Both operands are K-contiguous ("NT"), exactly nn.Linear's layout, so every MFMA fragment is one
 // 16-byte LDS read.  Design for gfx950:
 //   * 256x256x64 tile, 512 threads = 8 waves as 2(M) x 4(N); each wave owns 128x64 outputs as
-//     8x4 v_mfma_f32_16x16x32_bf16 accumulators (128 VGPRs).  The MFMA is issued "swapped"
+//     8x4 v_mfma_f32_16x16x32_{bf16,f16} accumulators (128 VGPRs).  The MFMA is issued "swapped"
 //     (D = Wfrag . Afrag^T) so that a lane's 4 accumulator registers are 4 consecutive n of one row m;
 //     the W rows are dealt to MFMA rows in an interleaved order so that two n-repeats give a lane
 //     8 consecutive n -> 16-byte global stores.
 //   * operands stream HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered
 //     (2 x 64 KiB); LDS images are lane-linear as the DMA requires, with the XOR bank swizzle applied
 //     on the SOURCE address and on the read (both-sides rule) -> conflict-free ds_read_b128.
+//   * conv mode: row m is an output voxel (t,h,w) of a channels-last [T,H,W,C] tensor and K runs over
+//     (tap, channel); the per-lane DMA source address is the tap-shifted voxel with its indices CLAMPED
+//     (= replicate padding, incl. the causal 2-frame front pad in T) and optionally halved (= the nearest
+//     upsample that precedes the conv in UpsampleCausal3D, first frame not repeated in T).  Padding and
+//     upsampling therefore cost no memory pass at all.
 //   * 1-D grid, remapped so each XCD gets a contiguous chunk of tiles (shared L2) and 32 co-resident
 //     tiles form a 4(M) x 8(N) patch (A and W panels are shared inside an XCD).
 // Algorithmic work: 2*M*N*K flop; HBM bytes >= 2*(M*K + N*K + M*N).
@@ -24,17 +30,41 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffered: 128 KiB
 constexpr int GROUP_M = 4;
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+struct BF16T {
+    typedef bf16x8 vec8;
+    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float lo(uint32_t w) { return bf2f_lo(w); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return bf2f_hi(w); }
+    static __device__ __forceinline__ uint32_t pack(float a, float b) { return pack_bf2(a, b); }
+    static __device__ __forceinline__ float round(float f) { return rbf(f); }
+};
+struct F16T {
+    typedef f16x8 vec8;
+    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+    static __device__ __forceinline__ uint32_t pack(float a, float b) {
+        return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b) << 16);
+    }
+    static __device__ __forceinline__ float round(float f) { return (float)(_Float16)f; }
+};
+
 struct GemmArgs {
-    const bf16_t* A; int64_t lda;
-    const bf16_t* W; int64_t ldw;
-    const bf16_t* bias;
+    const uint16_t* A; int64_t lda;
+    const uint16_t* W; int64_t ldw;
+    const uint16_t* bias;
     int M, N, K;
-    bf16_t* out0; int64_t ld0; int act0;
+    uint16_t* out0; int64_t ld0; int act0;
     int n_split;
-    bf16_t* out1; int64_t ld1; int act1;
-    const bf16_t* gate;
-    const bf16_t* res; int64_t ld_res;
+    uint16_t* out1; int64_t ld1; int act1;
+    const uint16_t* gate;
+    const uint16_t* res; int64_t ld_res;
+    float* out_f32;            // if set: plain fp32 result (acc + bias) to out_f32[m*ld0 + n], nothing else
     int tiles_m, tiles_n;
+    // conv mode (ksz = 3): output grid cT x cH x cW, source tensor sT x sH x sW (differs when upsampling), cin per tap
+    int cT, cH, cW, sT, sH, sW, up_t, up_hw, cin;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -49,7 +79,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs g) {
+template <typename DT, bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -71,13 +102,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs g) {
 
     // ---- per-thread staging addresses: 4 DMA pieces per operand per K-tile, each 512 thr x 16 B = 64 rows
     const int srow = tid >> 3, scp = tid & 7;  // row within a 64-row piece, 16-B chunk position in LDS
-    const bf16_t* a_src[4];
-    const bf16_t* w_src[4];
+    const uint16_t* a_src[4];
+    const uint16_t* w_src[4];
+    int vt[4], vh[4], vw[4];   // conv: output voxel of each staged row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = i * 64 + srow;
         const int ar = min(m0 + row, g.M - 1), wr = min(n0 + row, g.N - 1);  // clamp: tails read valid rows
-        a_src[i] = g.A + (int64_t)ar * g.lda + ((scp ^ swz_a(row)) << 3);
+        if (CONV) {
+            vw[i] = ar % g.cW;
+            const int th = ar / g.cW;
+            vh[i] = th % g.cH;
+            vt[i] = th / g.cH;
+            a_src[i] = g.A + ((scp ^ swz_a(row)) << 3);
+        } else {
+            a_src[i] = g.A + (int64_t)ar * g.lda + ((scp ^ swz_a(row)) << 3);
+        }
         w_src[i] = g.W + (int64_t)wr * g.ldw + ((scp ^ swz_w(row)) << 3);
     }
     const int wave_lds = wave * 1024;  // wave-uniform base of this wave's 1 KiB slice of each piece
@@ -85,14 +125,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs g) {
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE_BYTES + wave_lds;
         const int koff = kt * BK;
+        if (CONV) {
+            const int tap = koff / g.cin, c0 = koff - tap * g.cin;
+            const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + koff), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                int ti = max(vt[i] + dt - 2, 0);
+                int hi = min(max(vh[i] + dh - 1, 0), g.cH - 1);
+                int wi = min(max(vw[i] + dw - 1, 0), g.cW - 1);
+                if (g.up_t) ti = ti == 0 ? 0 : 1 + ((ti - 1) >> 1);
+                hi >>= g.up_hw;
+                wi >>= g.up_hw;
+                const int64_t srcrow = ((int64_t)ti * g.sH + hi) * g.sW + wi;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + srcrow * g.lda + c0), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + koff), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + koff), (lds_ptr_t)(base + TILE_BYTES + i * 8192), 16, 0, 0);
-        }
     };
 
     // ---- fragment read offsets (bytes inside an operand tile), k-step 0; k-step 1 flips chunk bit 2
@@ -120,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs g) {
     stage(0, 0);
     __syncthreads();  // (the compiler drains vmcnt before the barrier: DMA landed)
 
+    typedef typename DT::vec8 vec8;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
@@ -127,35 +182,41 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs g) {
         const char* Wt = At + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[8], wf[4];
+            vec8 af[8], wf[4];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(Wt + (w_off[ni] ^ (ks << 6)));
+            for (int ni = 0; ni < 4; ++ni) wf[ni] = *reinterpret_cast<const vec8*>(Wt + (w_off[ni] ^ (ks << 6)));
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(At + (a_off[mi] ^ (ks << 6)));
+            for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const vec8*>(At + (a_off[mi] ^ (ks << 6)));
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = DT::mfma(wf[ni], af[mi], acc[mi][ni]);
         }
         __syncthreads();
     }
 
     // ---- epilogue: lane holds, per (mi, n-repeat pair), 8 consecutive n of row m
+    auto unpack = [](const u32x4& w, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = DT::lo(w[i]);
+            f[2 * i + 1] = DT::hi(w[i]);
+        }
+    };
     const int mrow0 = m0 + wm * 128 + fr;
 #pragma unroll
     for (int np = 0; np < 2; ++np) {
         const int n = n0 + wn * 64 + np * 32 + fq * 8;
         if (n >= g.N) continue;
         float b[8], gt[8];
-        if (g.bias) unpack8(*reinterpret_cast<const u32x4*>(g.bias + n), b);
+        if (g.bias) unpack(*reinterpret_cast<const u32x4*>(g.bias + n), b);
         else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) b[j] = 0.f;
         }
-        if (g.gate) unpack8(*reinterpret_cast<const u32x4*>(g.gate + n), gt);
+        if (g.gate) unpack(*reinterpret_cast<const u32x4*>(g.gate + n), gt);
         const bool second = n >= g.n_split;
-        bf16_t* obase = second ? g.out1 + (n - g.n_split) : g.out0 + n;
+        uint16_t* obase = second ? g.out1 + (n - g.n_split) : g.out0 + n;
         const int64_t ldo = second ? g.ld1 : g.ld0;
         const int act = second ? g.act1 : g.act0;
 #pragma unroll
@@ -168,19 +229,65 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs g) {
                 v[r] = acc[mi][2 * np][r] + b[r];
                 v[4 + r] = acc[mi][2 * np + 1][r] + b[4 + r];
             }
+            if (g.out_f32) {
+                float4* o = reinterpret_cast<float4*>(g.out_f32 + (int64_t)m * g.ld0 + n);
+                o[0] = make_float4(v[0], v[1], v[2], v[3]);
+                o[1] = make_float4(v[4], v[5], v[6], v[7]);
+                continue;
+            }
             if (act) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = apply_act(rbf(v[j]), act);
+                for (int j = 0; j < 8; ++j) v[j] = apply_act(DT::round(v[j]), act);
             }
-            if (g.gate) {
+            if (g.res) {
                 float rs[8];
-                unpack8(*reinterpret_cast<const u32x4*>(g.res + (int64_t)m * g.ld_res + n), rs);
+                unpack(*reinterpret_cast<const u32x4*>(g.res + (int64_t)m * g.ld_res + n), rs);
+                if (g.gate) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = rs[j] + rbf(rbf(v[j]) * gt[j]);
+                    for (int j = 0; j < 8; ++j) v[j] = rs[j] + DT::round(DT::round(v[j]) * gt[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = rs[j] + DT::round(v[j]);
+                }
             }
-            *reinterpret_cast<u32x4*>(obase + (int64_t)m * ldo) = pack8(v);
+            u32x4 w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = DT::pack(v[2 * i], v[2 * i + 1]);
+            *reinterpret_cast<u32x4*>(obase + (int64_t)m * ldo) = w;
         }
     }
+}
+
+template <typename DT, bool CONV>
+int launch(GemmArgs& g, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_kernel<DT, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return HV_ERR_LAUNCH;
+        attr_set = true;
+    }
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    gemm_kernel<DT, CONV><<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS_BYTES, stream>>>(g);
+    return hv_check_launch();
+}
+
+int fill_common(GemmArgs& g, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, int M, int N, int K,
+                void* out0, int64_t ld0, int act0, int n_split, void* out1, int64_t ld1, int act1, const void* gate,
+                const void* res, int64_t ld_res) {
+    if (!A || !W || !out0 || M < 0 || N <= 0 || K < BK || (K % BK) || (N & 7) || (lda & 7) || (ldw & 7) || (ld0 & 7))
+        return HV_ERR_ARG;
+    if (n_split <= 0 || n_split > N) n_split = N;
+    if (n_split < N && (!out1 || (n_split & 7) || (ld1 & 7))) return HV_ERR_ARG;
+    if ((gate && !res) || (res && (ld_res & 7))) return HV_ERR_ARG;
+    if (act0 < 0 || act0 > 2 || act1 < 0 || act1 > 2) return HV_ERR_ARG;
+    g = GemmArgs{};
+    g.A = (const uint16_t*)A; g.lda = lda; g.W = (const uint16_t*)W; g.ldw = ldw; g.bias = (const uint16_t*)bias;
+    g.M = M; g.N = N; g.K = K;
+    g.out0 = (uint16_t*)out0; g.ld0 = ld0; g.act0 = act0; g.n_split = n_split;
+    g.out1 = (uint16_t*)out1; g.ld1 = ld1; g.act1 = act1;
+    g.gate = (const uint16_t*)gate; g.res = (const uint16_t*)res; g.ld_res = ld_res;
+    return HV_OK;
 }
 
 }  // namespace
@@ -188,26 +295,39 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmArgs g) {
 extern "C" int hv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, int M, int N, int K,
                             void* out0, int64_t ld0, int act0, int n_split, void* out1, int64_t ld1, int act1,
                             const void* gate, const void* res, int64_t ld_res, hipStream_t stream) {
-    if (!A || !W || !out0 || M < 0 || N <= 0 || K < BK || (K % BK) || (N & 7) || (lda & 7) || (ldw & 7) || (ld0 & 7))
-        return HV_ERR_ARG;
-    if (n_split <= 0 || n_split > N) n_split = N;
-    if (n_split < N && (!out1 || (n_split & 7) || (ld1 & 7))) return HV_ERR_ARG;
-    if ((gate != nullptr) != (res != nullptr) || (res && (ld_res & 7))) return HV_ERR_ARG;
-    if (act0 < 0 || act0 > 2 || act1 < 0 || act1 > 2) return HV_ERR_ARG;
-    if (M == 0) return HV_OK;
     GemmArgs g;
-    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = (const bf16_t*)bias;
-    g.M = M; g.N = N; g.K = K;
-    g.out0 = (bf16_t*)out0; g.ld0 = ld0; g.act0 = act0; g.n_split = n_split;
-    g.out1 = (bf16_t*)out1; g.ld1 = ld1; g.act1 = act1;
-    g.gate = (const bf16_t*)gate; g.res = (const bf16_t*)res; g.ld_res = ld_res;
-    g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return HV_ERR_LAUNCH;
-        attr_set = true;
+    int rc = fill_common(g, A, lda, W, ldw, bias, M, N, K, out0, ld0, act0, n_split, out1, ld1, act1, gate, res, ld_res);
+    if (rc != HV_OK) return rc;
+    if (M == 0) return HV_OK;
+    return launch<BF16T, false>(g, stream);
+}
+
+extern "C" int hv_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, int M, int N, int K,
+                           void* out, int64_t ldo, int out_is_f32, const void* res, int64_t ld_res, hipStream_t stream) {
+    GemmArgs g;
+    int rc = fill_common(g, A, lda, W, ldw, bias, M, N, K, out, ldo, 0, 0, nullptr, 0, 0, nullptr, res, ld_res);
+    if (rc != HV_OK) return rc;
+    if (out_is_f32) {
+        if (res) return HV_ERR_ARG;
+        g.out_f32 = (float*)out;
     }
-    gemm_bf16_kernel<<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS_BYTES, stream>>>(g);
-    return hv_check_launch();
+    if (M == 0) return HV_OK;
+    return launch<F16T, false>(g, stream);
+}
+
+extern "C" int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_taps, const void* bias, void* out, int64_t ldo,
+                                    int T, int H, int W, int Cin, int Cout, int up_t, int up_hw, const void* res,
+                                    int64_t ld_res, hipStream_t stream) {
+    // x: channels-last source [sT, sH, sW, >=Cin] (row stride ldx); output grid T x H x W (T = 1 + 2*(sT-1) when up_t,
+    // H = 2*sH, W = 2*sW when up_hw); w_taps: [Cout][27][Cin] f16.
+    if (T <= 0 || H <= 0 || W <= 0 || Cin < 64 || (Cin % 64) || Cout <= 0 || (up_t & ~1) || (up_hw & ~1)) return HV_ERR_ARG;
+    if ((int64_t)T * H * W > 0x7fffffff) return HV_ERR_ARG;
+    if ((up_t && !(T & 1)) || (up_hw && ((H & 1) || (W & 1)))) return HV_ERR_ARG;
+    GemmArgs g;
+    int rc = fill_common(g, x, ldx, w_taps, (int64_t)27 * Cin, bias, T * H * W, Cout, 27 * Cin, out, ldo, 0, 0, nullptr, 0, 0,
+                         nullptr, res, ld_res);
+    if (rc != HV_OK) return rc;
+    g.cT = T; g.cH = H; g.cW = W; g.cin = Cin; g.up_t = up_t; g.up_hw = up_hw;
+    g.sT = up_t ? (T + 1) / 2 : T; g.sH = H >> up_hw; g.sW = W >> up_hw;
+    return launch<F16T, true>(g, stream);
 }

@@ -1,0 +1,304 @@
+// HBM-bound kernels of the 3D causal VAE decode (K16, K18 softmax, K19, K20) on channels-last fp16 activations
+// [voxel = (t*H + h)*W + w][C].  The convolutions are hv_conv3d_causal_f16 (hv_gemm.hip).
+#include "hv_common.hpp"
+#include "../../include/hv_kernels.h"
+
+namespace {
+
+typedef _Float16 h16;
+__device__ __forceinline__ float h2f(uint16_t v) { return (float)__builtin_bit_cast(h16, v); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (h16)f); }
+__device__ __forceinline__ float rh(float f) { return (float)(h16)f; }
+__device__ __forceinline__ void unpack8h(const u32x4& w, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = h2f((uint16_t)(w[i] & 0xFFFFu));
+        f[2 * i + 1] = h2f((uint16_t)(w[i] >> 16));
+    }
+}
+__device__ __forceinline__ u32x4 pack8h(const float (&f)[8]) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2h(f[2 * i]) | ((uint32_t)f2h(f[2 * i + 1]) << 16);
+    return w;
+}
+
+// ---- GroupNorm pass 1: per-workgroup partial (sum, sumsq) per channel.  256 threads = (C/8) channel-threads x
+// (2048/C) row lanes; partial[blk][c][2] fp32.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restrict__ x, int64_t ldx, int64_t M, int C,
+                                                          float* __restrict__ partial, int rows_per_blk) {
+    extern __shared__ float red[];   // [row lanes][C][2]
+    const int cthreads = C >> 3;
+    const int ct = threadIdx.x % cthreads, rl = threadIdx.x / cthreads, nrl = 256 / cthreads;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    const int64_t r1 = min(M, r0 + rows_per_blk);
+    if (rl < nrl) {
+        for (int64_t r = r0 + rl; r < r1; r += nrl) {
+            float v[8];
+            unpack8h(*reinterpret_cast<const u32x4*>(x + r * ldx + ct * 8), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += v[j];
+                q[j] += v[j] * v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[(rl * C + ct * 8 + j) * 2] = s[j];
+            red[(rl * C + ct * 8 + j) * 2 + 1] = q[j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int l = 0; l < nrl; ++l) {
+            a += red[(l * C + c) * 2];
+            b += red[(l * C + c) * 2 + 1];
+        }
+        partial[((int64_t)blockIdx.x * C + c) * 2] = a;
+        partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+}
+
+// ---- GroupNorm pass 2 (one block): fold partials in fp64 -> per-channel affine y = x*sc[c] + sh[c]
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int groups,
+                                                           int64_t M, float eps, const uint16_t* __restrict__ w,
+                                                           const uint16_t* __restrict__ b, float* __restrict__ affine) {
+    __shared__ double gs[64], gq[64];
+    const int cpg = C / groups;
+    const int tpg = 256 / groups;          // threads per group (groups is a power of two <= 64 -> tpg in 4..256)
+    {
+        const int g = threadIdx.x / tpg, sub = threadIdx.x % tpg;
+        double s = 0.0, q = 0.0;
+        for (int k = sub; k < nblk; k += tpg)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                s += (double)partial[((int64_t)k * C + c) * 2];
+                q += (double)partial[((int64_t)k * C + c) * 2 + 1];
+            }
+        for (int o = (tpg < 64 ? tpg : 64) >> 1; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        if (tpg <= 64) {
+            if (sub == 0) { gs[g] = s; gq[g] = q; }
+        } else {   // a group spans several waves: combine the wave leaders through LDS atomics-free two-step
+            __shared__ double ws[4], wq[4];
+            if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = s; wq[threadIdx.x >> 6] = q; }
+            __syncthreads();
+            if (sub == 0) {
+                double a = 0.0, bq = 0.0;
+                for (int i = 0; i < tpg / 64; ++i) { a += ws[g * (tpg / 64) + i]; bq += wq[g * (tpg / 64) + i]; }
+                gs[g] = a; gq[g] = bq;
+            }
+        }
+    }
+    __syncthreads();
+    const double n = (double)M * cpg;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const double mean = gs[g] / n;
+        double var = gq[g] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float wc = h2f(w[c]), bc = h2f(b[c]);
+        affine[2 * c] = rstd * wc;
+        affine[2 * c + 1] = bc - (float)mean * rstd * wc;
+    }
+}
+
+// ---- GroupNorm pass 3: y = [silu](x*sc + sh) -> fp16
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
+                                                        int64_t ldy, int64_t M, int C, const float* __restrict__ affine, int silu) {
+    const int cvec = C >> 3;
+    const int64_t total = M * cvec;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cvec;
+        const int c = (int)(i % cvec) * 8;
+        float v[8], o[8];
+        unpack8h(*reinterpret_cast<const u32x4*>(x + r * ldx + c), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = v[j] * affine[2 * (c + j)] + affine[2 * (c + j) + 1];
+            o[j] = silu ? silu_f(t) : t;
+        }
+        *reinterpret_cast<u32x4*>(y + r * ldy + c) = pack8h(o);
+    }
+}
+
+// ---- row softmax: P[r][c] = softmax_c(scale * S[r][c]) for c < cols, 0 for cols <= c < cols_pad; fp32 in, fp16 out
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds_, uint16_t* __restrict__ P,
+                                                            int64_t ldp, int rows, int cols, int cols_pad, float scale) {
+    __shared__ float redm[4], reds[4];
+    const int r = blockIdx.x;
+    const float* s = S + (int64_t)r * lds_;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, s[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])) * scale;
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) sum += __expf(s[c] * scale - m);
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) reds[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (reds[0] + reds[1] + reds[2] + reds[3]);
+    uint16_t* p = P + (int64_t)r * ldp;
+    for (int c = threadIdx.x; c < cols_pad; c += 256) p[c] = c < cols ? f2h(__expf(s[c] * scale - m) * inv) : (uint16_t)0;
+}
+
+// ---- transpose [R][C] (row stride lds) -> [C][R] (row stride ldd), 16-bit elements, 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ src, int64_t lds_, uint16_t* __restrict__ dst,
+                                                           int64_t ldd, int R, int C) {
+    __shared__ uint16_t tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(int64_t)(r0 + i) * lds_ + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) dst[(int64_t)(c0 + i) * ldd + r0 + tx] = tile[tx][i];
+}
+
+// ---- latent crop: z fp32 [C,T,H,W] (strides sc,st,sh,sw) region -> channels-last fp16 [t][h][w][Cpad], zero padded channels
+__global__ __launch_bounds__(256) void latent_tile_kernel(const float* __restrict__ z, int64_t sc, int64_t st, int64_t sh,
+                                                           int64_t sw, int C, int T, int H, int W, int Cpad,
+                                                           uint16_t* __restrict__ out) {
+    const int64_t n = (int64_t)T * H * W * Cpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        int64_t v = i / Cpad;
+        const int w = (int)(v % W);
+        v /= W;
+        const int h = (int)(v % H);
+        const int t = (int)(v / H);
+        out[i] = c < C ? f2h(z[c * sc + t * st + h * sh + w * sw]) : (uint16_t)0;
+    }
+}
+
+// ---- generic strided 4-D fp16 ops on [C,T,H,W] index space
+struct View4 { int64_t s[4]; };
+__device__ __forceinline__ void idx4(int64_t i, const int* dims, int (&ix)[4]) {
+    ix[3] = (int)(i % dims[3]); i /= dims[3];
+    ix[2] = (int)(i % dims[2]); i /= dims[2];
+    ix[1] = (int)(i % dims[1]);
+    ix[0] = (int)(i / dims[1]);
+}
+
+struct Dims4 { int d[4]; };
+
+// b[idx] = f16( f16(a[idx shifted] * (1 - y/E)) + f16(b[idx] * (y/E)) ), y = idx[axis] in [0,E)   (blend_v/h/t)
+__global__ __launch_bounds__(256) void blend_kernel(const uint16_t* __restrict__ a, View4 sa, uint16_t* __restrict__ b, View4 sb,
+                                                     Dims4 dims, int axis, int extent) {
+    const int64_t n = (int64_t)dims.d[0] * dims.d[1] * dims.d[2] * dims.d[3];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int ix[4];
+        idx4(i, dims.d, ix);
+        const int y = ix[axis];
+        const float wa = (float)(1.0 - (double)y / (double)extent), wb = (float)((double)y / (double)extent);
+        const int64_t oa = ix[0] * sa.s[0] + ix[1] * sa.s[1] + ix[2] * sa.s[2] + ix[3] * sa.s[3];
+        const int64_t ob = ix[0] * sb.s[0] + ix[1] * sb.s[1] + ix[2] * sb.s[2] + ix[3] * sb.s[3];
+        b[ob] = f2h(rh(h2f(a[oa]) * wa) + rh(h2f(b[ob]) * wb));
+    }
+}
+
+__global__ __launch_bounds__(256) void copy4d_kernel(const uint16_t* __restrict__ src, View4 ss, uint16_t* __restrict__ dst, View4 sd,
+                                                      Dims4 dims) {
+    const int64_t n = (int64_t)dims.d[0] * dims.d[1] * dims.d[2] * dims.d[3];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int ix[4];
+        idx4(i, dims.d, ix);
+        dst[ix[0] * sd.s[0] + ix[1] * sd.s[1] + ix[2] * sd.s[2] + ix[3] * sd.s[3]] =
+            src[ix[0] * ss.s[0] + ix[1] * ss.s[1] + ix[2] * ss.s[2] + ix[3] * ss.s[3]];
+    }
+}
+
+// out_f32 = clamp(f16(f16(x/2) + 0.5), 0, 1)   (pipeline_hunyuan_video.py:1090-1092)
+__global__ __launch_bounds__(256) void postprocess_kernel(const uint16_t* __restrict__ x, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = rh(rh(h2f(x[i]) * 0.5f) + 0.5f);
+        out[i] = fminf(fmaxf(v, 0.f), 1.f);
+    }
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int hv_groupnorm_affine_f16(const void* x, int64_t ldx, int64_t M, int C, int groups, float eps, const void* weight,
+                                       const void* bias, float* partial_ws, int64_t partial_ws_floats, float* affine_out,
+                                       hipStream_t stream) {
+    if (!x || !weight || !bias || !partial_ws || !affine_out || M <= 0 || C < 8 || (C & 7) || C > 2048 || groups <= 0 ||
+        groups > 64 || (groups & (groups - 1)) || (C % groups) || (ldx & 7))
+        return HV_ERR_ARG;
+    const int cthreads = C / 8;
+    if (cthreads > 256 || (256 % cthreads)) return HV_ERR_ARG;
+    const int nrl = 256 / cthreads;
+    int nblk = (int)((M + 2047) / 2048);
+    if (nblk > 1024) nblk = 1024;
+    if ((int64_t)nblk * C * 2 > partial_ws_floats) nblk = (int)(partial_ws_floats / (2 * C));
+    if (nblk < 1) return HV_ERR_ARG;
+    const int rows_per_blk = (int)((M + nblk - 1) / nblk);
+    gn_partial_kernel<<<dim3(nblk), dim3(256), (size_t)nrl * C * 2 * sizeof(float), stream>>>((const uint16_t*)x, ldx, M, C,
+                                                                                            partial_ws, rows_per_blk);
+    gn_finalize_kernel<<<dim3(1), dim3(256), 0, stream>>>(partial_ws, nblk, C, groups, M, eps, (const uint16_t*)weight,
+                                                          (const uint16_t*)bias, affine_out);
+    return hv_check_launch();
+}
+
+extern "C" int hv_groupnorm_apply_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int C, const float* affine,
+                                      int silu, hipStream_t stream) {
+    if (!x || !y || !affine || M <= 0 || C < 8 || (C & 7) || (ldx & 7) || (ldy & 7)) return HV_ERR_ARG;
+    gn_apply_kernel<<<dim3(grid_for(M * (C / 8))), dim3(256), 0, stream>>>((const uint16_t*)x, ldx, (uint16_t*)y, ldy, M, C, affine, silu);
+    return hv_check_launch();
+}
+
+extern "C" int hv_softmax_rows_f32_f16(const float* S, int64_t ld_s, void* P, int64_t ld_p, int rows, int cols, int cols_pad,
+                                       float scale, hipStream_t stream) {
+    if (!S || !P || rows <= 0 || cols <= 0 || cols_pad < cols) return HV_ERR_ARG;
+    softmax_rows_kernel<<<dim3(rows), dim3(256), 0, stream>>>(S, ld_s, (uint16_t*)P, ld_p, rows, cols, cols_pad, scale);
+    return hv_check_launch();
+}
+
+extern "C" int hv_transpose_16b(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C, hipStream_t stream) {
+    if (!src || !dst || R <= 0 || C <= 0) return HV_ERR_ARG;
+    transpose16_kernel<<<dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, stream>>>((const uint16_t*)src, ld_src, (uint16_t*)dst, ld_dst, R, C);
+    return hv_check_launch();
+}
+
+extern "C" int hv_vae_latent_tile_f16(const float* z, int64_t sc, int64_t st, int64_t sh, int64_t sw, int C, int T, int H, int W,
+                                      int Cpad, void* out, hipStream_t stream) {
+    if (!z || !out || C <= 0 || T <= 0 || H <= 0 || W <= 0 || Cpad < C) return HV_ERR_ARG;
+    latent_tile_kernel<<<dim3(grid_for((int64_t)T * H * W * Cpad)), dim3(256), 0, stream>>>(z, sc, st, sh, sw, C, T, H, W, Cpad, (uint16_t*)out);
+    return hv_check_launch();
+}
+
+extern "C" int hv_vae_blend_f16(const void* a, const int64_t* a_strides, void* b, const int64_t* b_strides, const int* dims,
+                                int axis, int extent, hipStream_t stream) {
+    if (!a || !b || !a_strides || !b_strides || !dims || axis < 0 || axis > 3 || extent <= 0 || dims[axis] > extent) return HV_ERR_ARG;
+    View4 sa, sb;
+    Dims4 d;
+    for (int i = 0; i < 4; ++i) { sa.s[i] = a_strides[i]; sb.s[i] = b_strides[i]; d.d[i] = dims[i]; if (dims[i] <= 0) return HV_ERR_ARG; }
+    blend_kernel<<<dim3(grid_for((int64_t)d.d[0] * d.d[1] * d.d[2] * d.d[3])), dim3(256), 0, stream>>>((const uint16_t*)a, sa, (uint16_t*)b, sb, d, axis, extent);
+    return hv_check_launch();
+}
+
+extern "C" int hv_copy4d_16b(const void* src, const int64_t* src_strides, void* dst, const int64_t* dst_strides, const int* dims,
+                             hipStream_t stream) {
+    if (!src || !dst || !src_strides || !dst_strides || !dims) return HV_ERR_ARG;
+    View4 ss, sd;
+    Dims4 d;
+    for (int i = 0; i < 4; ++i) { ss.s[i] = src_strides[i]; sd.s[i] = dst_strides[i]; d.d[i] = dims[i]; if (dims[i] <= 0) return HV_ERR_ARG; }
+    copy4d_kernel<<<dim3(grid_for((int64_t)d.d[0] * d.d[1] * d.d[2] * d.d[3])), dim3(256), 0, stream>>>((const uint16_t*)src, ss, (uint16_t*)dst, sd, d);
+    return hv_check_launch();
+}
+
+extern "C" int hv_vae_postprocess_f16_f32(const void* x, float* out, int64_t n, hipStream_t stream) {
+    if (!x || !out || n <= 0) return HV_ERR_ARG;
+    postprocess_kernel<<<dim3(grid_for(n)), dim3(256), 0, stream>>>((const uint16_t*)x, out, n);
+    return hv_check_launch();
+}

@@ -1,0 +1,335 @@
+"""AutoencoderKLCausal3D - decode side - on the MI355X kernels, with the reference's call surface
+(hyvideo/vae/autoencoder_kl_causal_3d.py: decode(z, return_dict, generator)[0], enable_tiling(), .config.*, .dtype)
+and the reference's state-dict key names for `decoder.*` and `post_quant_conv.*` (vae/vae.py:139-226,
+vae/unet_causal_3d_blocks.py).  The encoder is out of scope for the denoise+decode hot path;
+checkpoint keys under `encoder.` / `quant_conv.` are ignored on load.
+
+Execution model: activations are fp16 CHANNELS-LAST ([T*H*W voxels, C]) so that
+  * CausalConv3d is an implicit GEMM whose A rows are contiguous channel vectors (replicate padding = index clamp,
+    nearest upsample = index halving, both inside the DMA gather: K15+K17 cost no extra memory pass),
+  * GroupNorm is a per-channel affine after a two-level reduction (K16),
+  * the mid-block attention needs no rearrange: "b (f h w) c" IS this layout (K18); the frame-causal mask is realised by
+    giving frame f's queries exactly the keys of frames <= f (no [L,L] mask tensor - the reference builds a 606 MB one),
+  * tiles are decoded one after another and blended in the reference's exact order (K19) by strided kernels.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import synthetic as syn
+from .. import vae_ops as V
+
+F16 = torch.float16
+
+
+def _r(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _build_tree(root: nn.Module, shapes: Dict[str, Tuple[int, ...]], device, dtype):
+    """Create nested parameter holders so that root.state_dict() has exactly the keys of `shapes`."""
+    for key, shp in shapes.items():
+        parts = key.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        mod.register_parameter(parts[-1], nn.Parameter(torch.empty(*shp, device=device, dtype=dtype), requires_grad=False))
+
+
+class AutoencoderKLCausal3D(nn.Module):
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, down_block_types=("DownEncoderBlockCausal3D",) * 4,
+                 up_block_types=("UpDecoderBlockCausal3D",) * 4, block_out_channels=syn.VAE_BLOCK_OUT_CHANNELS,
+                 layers_per_block: int = 2, act_fn: str = "silu", latent_channels: int = 16, norm_num_groups: int = 32,
+                 sample_size: int = 256, sample_tsize: int = 64, scaling_factor: float = 0.476986,
+                 force_upcast: bool = True, spatial_compression_ratio: int = 8, time_compression_ratio: int = 4,
+                 mid_block_add_attention: bool = True, device=None, dtype=F16):
+        super().__init__()
+        if act_fn not in ("silu", "swish") or norm_num_groups != 32 or time_compression_ratio != 4 or \
+                spatial_compression_ratio != 8 or not mid_block_add_attention or len(block_out_channels) != 4:
+            raise NotImplementedError("kernels cover the shipped 884 VAE topology (SiLU, GroupNorm(32), 4 blocks, mid attention)")
+        self.config = SimpleNamespace(in_channels=in_channels, out_channels=out_channels, down_block_types=down_block_types,
+                                      up_block_types=up_block_types, block_out_channels=tuple(block_out_channels),
+                                      layers_per_block=layers_per_block, act_fn=act_fn, latent_channels=latent_channels,
+                                      norm_num_groups=norm_num_groups, sample_size=sample_size, sample_tsize=sample_tsize,
+                                      scaling_factor=scaling_factor, force_upcast=force_upcast,
+                                      spatial_compression_ratio=spatial_compression_ratio,
+                                      time_compression_ratio=time_compression_ratio, mid_block_add_attention=mid_block_add_attention)
+        self.time_compression_ratio = time_compression_ratio
+        self._shapes = syn.vae_decoder_param_shapes(block_out_channels, latent_channels, out_channels, layers_per_block)
+        _build_tree(self, self._shapes, device, dtype)
+        self.use_slicing = False
+        self.use_spatial_tiling = False
+        self.use_temporal_tiling = False
+        # autoencoder_kl_causal_3d.py:117-132
+        self.tile_sample_min_tsize = sample_tsize
+        self.tile_latent_min_tsize = sample_tsize // time_compression_ratio
+        self.tile_sample_min_size = sample_size
+        self.tile_latent_min_size = int(sample_size / (2 ** (len(block_out_channels) - 1)))
+        self.tile_overlap_factor = 0.25
+        self._prep = None
+
+    # ------------------------------------------------------------------ reference surface
+    @property
+    def dtype(self):
+        return self.post_quant_conv.weight.dtype
+
+    @property
+    def device(self):
+        return self.post_quant_conv.weight.device
+
+    def enable_temporal_tiling(self, use_tiling: bool = True):
+        self.use_temporal_tiling = use_tiling
+
+    def disable_temporal_tiling(self):
+        self.enable_temporal_tiling(False)
+
+    def enable_spatial_tiling(self, use_tiling: bool = True):
+        self.use_spatial_tiling = use_tiling
+
+    def disable_spatial_tiling(self):
+        self.enable_spatial_tiling(False)
+
+    def enable_tiling(self, use_tiling: bool = True):
+        self.enable_spatial_tiling(use_tiling)
+        self.enable_temporal_tiling(use_tiling)
+
+    def disable_tiling(self):
+        self.disable_spatial_tiling()
+        self.disable_temporal_tiling()
+
+    def enable_slicing(self):
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        kept = {k: v for k, v in state_dict.items() if not (k.startswith("encoder.") or k.startswith("quant_conv."))}
+        self._prep = None
+        return super().load_state_dict(kept, strict=strict, assign=assign)
+
+    # ------------------------------------------------------------------ weight preparation (once)
+    def _prepare(self):
+        if self._prep is not None:
+            return self._prep
+        sd = {k: p.detach() for k, p in self.named_parameters()}
+        dev = self.device
+        P = {}
+
+        def conv3(name):
+            w, b = sd[name + ".weight"].to(F16), sd[name + ".bias"].to(F16)
+            co, ci = w.shape[0], w.shape[1]
+            cop, cip = _r(co, 8), _r(ci, 64)
+            wt = torch.zeros(cop, 27, cip, dtype=F16, device=dev)
+            wt[:co, :, :ci] = w.permute(0, 2, 3, 4, 1).reshape(co, 27, ci)      # [Cout][(dt,dh,dw)][Cin]
+            bp = torch.zeros(cop, dtype=F16, device=dev)
+            bp[:co] = b
+            P[name] = (wt.contiguous(), bp, cip, cop)
+
+        def lin(name, w, b, kpad=64):
+            w, b = w.to(F16), b.to(F16)
+            n, k = w.shape
+            wp = torch.zeros(_r(n, 8), _r(k, kpad), dtype=F16, device=dev)
+            wp[:n, :k] = w
+            bp = torch.zeros(_r(n, 8), dtype=F16, device=dev)
+            bp[:n] = b
+            P[name] = (wp, bp)
+
+        for k in sd:
+            if k.endswith(".weight") and sd[k].dim() == 5:
+                name = k[:-len(".weight")]
+                if sd[k].shape[-1] == 3:
+                    conv3(name)
+                else:
+                    lin(name, sd[k].reshape(sd[k].shape[0], -1), sd[name + ".bias"])
+            elif k.endswith(".weight") and sd[k].dim() == 1:
+                name = k[:-len(".weight")]
+                P[name] = (sd[k].to(F16).contiguous(), sd[name + ".bias"].to(F16).contiguous())
+        a = "decoder.mid_block.attentions.0."
+        wqkv = torch.cat([sd[a + n + ".weight"] for n in ("to_q", "to_k", "to_v")], 0)
+        bqkv = torch.cat([sd[a + n + ".bias"] for n in ("to_q", "to_k", "to_v")], 0)
+        lin(a + "qkv", wqkv, bqkv)
+        lin(a + "to_out.0", sd[a + "to_out.0.weight"], sd[a + "to_out.0.bias"])
+        self._prep = P
+        return P
+
+    # ------------------------------------------------------------------ decoder on one latent tile
+    @staticmethod
+    def _pad_channels(x, c_pad):
+        """Channel counts that are not a multiple of 64 (reduced test models only; the shipped VAE has 128/256/512):
+        zero-pad the rows so the K=64 DMA pieces never run into the next voxel."""
+        if x.shape[1] >= c_pad:
+            return x
+        xp = torch.zeros(x.shape[0], c_pad, dtype=F16, device=x.device)
+        V.copy4d_(x[None, None], xp[None, None, :, :x.shape[1]])
+        return xp
+
+    def _conv(self, P, name, x, T, H, W, up_t=False, up_hw=False, res=None):
+        wt, b, cip, cop = P[name]
+        return V.conv3d_causal(self._pad_channels(x, cip), wt, b, T, H, W, cip, cop, up_t, up_hw, res)
+
+    def _gn(self, P, name, x, silu=True):
+        w, b = P[name]
+        return V.groupnorm_apply(x, V.groupnorm_affine(x, w, b, 32, 1e-6), silu)
+
+    def _resnet(self, P, pre, x, T, H, W):
+        h = self._gn(P, pre + "norm1", x)
+        h = self._conv(P, pre + "conv1.conv", h, T, H, W)
+        h = self._gn(P, pre + "norm2", h)
+        if (pre + "conv_shortcut.conv") in P:
+            ws, bs = P[pre + "conv_shortcut.conv"]
+            x = V.gemm_f16(self._pad_channels(x, ws.shape[1]), ws, bs, k=ws.shape[1])
+        return self._conv(P, pre + "conv2.conv", h, T, H, W, res=x)
+
+    def _mid_attention(self, P, pre, x, T, HW):
+        L, C = x.shape
+        n = self._gn(P, pre + "group_norm", x, silu=False)
+        wqkv, bqkv = P[pre + "qkv"]
+        qkv = torch.zeros(_r(L, 8) + 8, 3 * C, dtype=F16, device=x.device)
+        V.gemm_f16(n, wqkv, bqkv, out=qkv[:L])
+        Lp = _r(L, 64)
+        vT = torch.zeros(C, Lp, dtype=F16, device=x.device)
+        V.transpose_16b(qkv[:L, 2 * C:], vT)
+        a = torch.empty(L, C, dtype=F16, device=x.device)
+        scale = 1.0 / math.sqrt(C)
+        S = torch.empty(HW, _r(L, 8), dtype=torch.float32, device=x.device)
+        Pm = torch.empty(HW, Lp, dtype=F16, device=x.device)
+        for f in range(T):
+            nk = (f + 1) * HW
+            nk8, nk64 = _r(nk, 8), _r(nk, 64)
+            q = qkv[f * HW:(f + 1) * HW, :C]
+            V.gemm_f16(q, qkv[:, C:2 * C], None, out=S, out_f32=True, n=nk8, k=C)
+            V.softmax_rows(S, nk, nk64, scale, out=Pm)
+            V.gemm_f16(Pm, vT, None, out=a[f * HW:(f + 1) * HW], n=C, k=nk64)
+        wo, bo = P[pre + "to_out.0"]
+        return V.gemm_f16(a, wo, bo, res=x, k=wo.shape[1])
+
+    def _decode_tile(self, z_view: torch.Tensor) -> Tuple[torch.Tensor, int, int, int]:
+        """z_view: fp32 [C,T,H,W] strided view -> (channels-last fp16 [T'*H'*W', 8] (3 valid channels), T', H', W')."""
+        P = self._prepare()
+        c, T, H, W = z_view.shape
+        x = V.latent_tile(z_view, 64)
+        wpq, bpq = P["post_quant_conv"]
+        x1 = torch.zeros(T * H * W, 64, dtype=F16, device=x.device)
+        V.gemm_f16(x, wpq, bpq, out=x1, n=wpq.shape[0], k=64)
+        pre = "decoder."
+        h = self._conv(P, pre + "conv_in.conv", x1, T, H, W)
+        h = self._resnet(P, pre + "mid_block.resnets.0.", h, T, H, W)
+        h = self._mid_attention(P, pre + "mid_block.attentions.0.", h, T, H * W)
+        h = self._resnet(P, pre + "mid_block.resnets.1.", h, T, H, W)
+        boc = self.config.block_out_channels
+        nb = len(boc)
+        for i in range(nb):
+            for j in range(self.config.layers_per_block + 1):
+                h = self._resnet(P, f"{pre}up_blocks.{i}.resnets.{j}.", h, T, H, W)
+            sp = i < 3
+            tm = (i >= nb - 1 - 2) and (i != nb - 1)
+            if sp or tm:
+                T2, H2, W2 = (1 + 2 * (T - 1) if tm else T), (2 * H if sp else H), (2 * W if sp else W)
+                h = self._conv(P, f"{pre}up_blocks.{i}.upsamplers.0.conv.conv", h, T2, H2, W2, up_t=tm, up_hw=sp)
+                T, H, W = T2, H2, W2
+        h = self._gn(P, pre + "conv_norm_out", h)
+        out = self._conv(P, pre + "conv_out.conv", h, T, H, W)
+        return out, T, H, W
+
+    # ------------------------------------------------------------------ tiling (reference loop order)
+    @staticmethod
+    def _cl_view(buf, T, H, W, c=3):
+        """[C,T,H,W] strided view of a channels-last [T*H*W, 8] buffer."""
+        return buf.as_strided((c, T, H, W), (1, H * W * buf.stride(0), W * buf.stride(0), buf.stride(0)), buf.storage_offset())
+
+    def _plain_decode(self, z4):
+        buf, T, H, W = self._decode_tile(z4)
+        out = torch.empty(3, T, H, W, dtype=F16, device=buf.device)
+        V.copy4d_(self._cl_view(buf, T, H, W), out)
+        return out
+
+    def _spatial_tiled_decode(self, z4):
+        """autoencoder_kl_causal_3d.py:422-469 on a [C,T,H,W] view; returns planar fp16 [3,T',H',W']."""
+        ov = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
+        ext = int(self.tile_sample_min_size * self.tile_overlap_factor)
+        lim = self.tile_sample_min_size - ext
+        rows = []
+        for i in range(0, z4.shape[-2], ov):
+            row = []
+            for j in range(0, z4.shape[-1], ov):
+                buf, T, H, W = self._decode_tile(z4[:, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size])
+                row.append(self._cl_view(buf, T, H, W))
+            rows.append(row)
+        heights = [min(r[0].shape[2], lim) for r in rows]
+        widths = [min(t.shape[3], lim) for t in rows[0]]
+        T = rows[0][0].shape[1]
+        out = torch.empty(3, T, sum(heights), sum(widths), dtype=F16, device=z4.device)
+        y0 = 0
+        for i, row in enumerate(rows):
+            x0 = 0
+            for j, tile in enumerate(row):
+                if i > 0:
+                    a = rows[i - 1][j]
+                    e = min(a.shape[2], tile.shape[2], ext)
+                    V.blend_(a[:, :, a.shape[2] - e:, :], tile[:, :, :e, :], 2, e)
+                if j > 0:
+                    a = row[j - 1]
+                    e = min(a.shape[3], tile.shape[3], ext)
+                    V.blend_(a[:, :, :, a.shape[3] - e:], tile[:, :, :, :e], 3, e)
+                V.copy4d_(tile[:, :, :heights[i], :widths[j]], out[:, :, y0:y0 + heights[i], x0:x0 + widths[j]])
+                x0 += widths[j]
+            y0 += heights[i]
+        return out
+
+    def _temporal_tiled_decode(self, z4):
+        """autoencoder_kl_causal_3d.py:510-541."""
+        T = z4.shape[1]
+        ov = int(self.tile_latent_min_tsize * (1 - self.tile_overlap_factor))
+        ext = int(self.tile_sample_min_tsize * self.tile_overlap_factor)
+        lim = self.tile_sample_min_tsize - ext
+        row = []
+        for i in range(0, T, ov):
+            tile = z4[:, i:i + self.tile_latent_min_tsize + 1]
+            if self.use_spatial_tiling and (tile.shape[-1] > self.tile_latent_min_size or tile.shape[-2] > self.tile_latent_min_size):
+                dec = self._spatial_tiled_decode(tile)
+            else:
+                dec = self._plain_decode(tile)
+            if i > 0:
+                dec = dec[:, 1:]
+            row.append(dec)
+        lens = [min(t.shape[1], lim + (1 if i == 0 else 0)) for i, t in enumerate(row)]
+        out = torch.empty(3, sum(lens), row[0].shape[2], row[0].shape[3], dtype=F16, device=z4.device)
+        t0 = 0
+        for i, tile in enumerate(row):
+            if i > 0:
+                a = row[i - 1]
+                e = min(a.shape[1], tile.shape[1], ext)
+                V.blend_(a[:, a.shape[1] - e:], tile[:, :e], 1, e)
+            V.copy4d_(tile[:, :lens[i]], out[:, t0:t0 + lens[i]])
+            t0 += lens[i]
+        return out
+
+    def _decode(self, z: torch.Tensor):
+        assert len(z.shape) == 5, "The input tensor should have 5 dimensions."
+        if z.shape[0] != 1:
+            raise NotImplementedError("batch 1 (use_slicing splits larger batches)")
+        z4 = z[0].to(torch.float32)
+        if self.use_temporal_tiling and z4.shape[1] > self.tile_latent_min_tsize:
+            return self._temporal_tiled_decode(z4)[None]
+        if self.use_spatial_tiling and (z4.shape[-1] > self.tile_latent_min_size or z4.shape[-2] > self.tile_latent_min_size):
+            return self._spatial_tiled_decode(z4)[None]
+        return self._plain_decode(z4)[None]
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None):
+        """autoencoder_kl_causal_3d.py:316-342: returns (sample,) or an object with .sample; sample fp16 [B,3,T,H,W]."""
+        if self.use_slicing and z.shape[0] > 1:
+            decoded = torch.cat([self._decode(zs) for zs in z.split(1)])
+        else:
+            decoded = self._decode(z)
+        if not return_dict:
+            return (decoded,)
+        return SimpleNamespace(sample=decoded)

@@ -1,0 +1,139 @@
+"""Tensor-level wrappers over the VAE-decode entry points of the C ABI (include/hv_kernels.h).  fp16, channels-last."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from .ops import _chk, _ptr, _stream
+
+F16 = torch.float16
+
+
+def _i64x4(v: Sequence[int]):
+    return (C.c_int64 * 4)(*[int(x) for x in v])
+
+
+def _i32x4(v: Sequence[int]):
+    return (C.c_int * 4)(*[int(x) for x in v])
+
+
+def gemm_f16(a, w, bias=None, out=None, out_f32: bool = False, res=None, n: Optional[int] = None, k: Optional[int] = None):
+    """out[M, n] = a[M, k] @ w[n, k]^T + bias (+ res).  a/w/out are 2-D views (row strides free)."""
+    _chk(a, F16, "a"), _chk(w, F16, "w")
+    m = a.shape[0]
+    k = a.shape[1] if k is None else k
+    n = w.shape[0] if n is None else n
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32 if out_f32 else F16, device=a.device)
+    _chk(out, torch.float32 if out_f32 else F16, "out")
+    if bias is not None:
+        _chk(bias, F16, "bias")
+    ld_res = 0
+    if res is not None:
+        _chk(res, F16, "res")
+        ld_res = res.stride(0)
+    _lib.check(_lib.load().hv_gemm_f16(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), m, n, k, _ptr(out), out.stride(0),
+                                       1 if out_f32 else 0, _ptr(res), ld_res, _stream()), "hv_gemm_f16")
+    return out
+
+
+def conv3d_causal(x, w_taps, bias, T: int, H: int, W: int, cin: int, cout: int, up_t: bool = False, up_hw: bool = False,
+                  res=None, out=None):
+    """x: channels-last source rows [sT*sH*sW, >=cin]; returns [T*H*W, cout] fp16."""
+    _chk(x, F16, "x"), _chk(w_taps, F16, "w_taps")
+    assert w_taps.is_contiguous() and w_taps.numel() == cout * 27 * cin, (w_taps.shape, cout, cin)
+    if out is None:
+        out = torch.empty(T * H * W, cout, dtype=F16, device=x.device)
+    ld_res = 0
+    if res is not None:
+        _chk(res, F16, "res")
+        ld_res = res.stride(0)
+    _lib.check(_lib.load().hv_conv3d_causal_f16(_ptr(x), x.stride(0), _ptr(w_taps), _ptr(bias), _ptr(out), out.stride(0), T, H, W,
+                                                cin, cout, int(up_t), int(up_hw), _ptr(res), ld_res, _stream()),
+               "hv_conv3d_causal_f16")
+    return out
+
+
+_gn_ws = {}
+
+
+def groupnorm_affine(x, weight, bias, groups: int = 32, eps: float = 1e-6):
+    """per-channel (scale, shift) fp32 [C, 2] of GroupNorm(groups) over all rows of x [M, C]."""
+    _chk(x, F16, "x"), _chk(weight, F16, "weight"), _chk(bias, F16, "bias")
+    m, c = x.shape
+    key = (str(x.device), c)
+    ws = _gn_ws.get(key)
+    if ws is None:
+        ws = torch.empty(1024 * c * 2, dtype=torch.float32, device=x.device)
+        _gn_ws[key] = ws
+    aff = torch.empty(c, 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().hv_groupnorm_affine_f16(_ptr(x), x.stride(0), m, c, groups, eps, _ptr(weight), _ptr(bias), _ptr(ws),
+                                                   ws.numel(), _ptr(aff), _stream()), "hv_groupnorm_affine_f16")
+    return aff
+
+
+def groupnorm_apply(x, affine, silu: bool, out=None):
+    _chk(x, F16, "x"), _chk(affine, torch.float32, "affine")
+    m, c = x.shape
+    if out is None:
+        out = torch.empty(m, c, dtype=F16, device=x.device)
+    _lib.check(_lib.load().hv_groupnorm_apply_f16(_ptr(x), x.stride(0), _ptr(out), out.stride(0), m, c, _ptr(affine), int(silu),
+                                                  _stream()), "hv_groupnorm_apply_f16")
+    return out
+
+
+def softmax_rows(s_f32, cols: int, cols_pad: int, scale: float, out=None):
+    _chk(s_f32, torch.float32, "S")
+    rows = s_f32.shape[0]
+    if out is None:
+        out = torch.empty(rows, cols_pad, dtype=F16, device=s_f32.device)
+    _lib.check(_lib.load().hv_softmax_rows_f32_f16(_ptr(s_f32), s_f32.stride(0), _ptr(out), out.stride(0), rows, cols, cols_pad,
+                                                   scale, _stream()), "hv_softmax_rows_f32_f16")
+    return out
+
+
+def transpose_16b(src, dst):
+    """dst[c, r] = src[r, c] for 2-D 16-bit views."""
+    assert src.element_size() == 2 and dst.element_size() == 2 and src.is_cuda and dst.is_cuda
+    r, c = src.shape
+    _lib.check(_lib.load().hv_transpose_16b(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), r, c, _stream()), "hv_transpose_16b")
+    return dst
+
+
+def latent_tile(z_f32_view, cpad: int):
+    """z view [C,T,H,W] fp32 (any strides) -> channels-last fp16 [T*H*W, cpad]."""
+    _chk(z_f32_view, torch.float32, "z", False)
+    c, t, h, w = z_f32_view.shape
+    sc, st, sh, sw = z_f32_view.stride()
+    out = torch.empty(t * h * w, cpad, dtype=F16, device=z_f32_view.device)
+    _lib.check(_lib.load().hv_vae_latent_tile_f16(_ptr(z_f32_view), sc, st, sh, sw, c, t, h, w, cpad, _ptr(out), _stream()),
+               "hv_vae_latent_tile_f16")
+    return out
+
+
+def blend_(a_view, b_view, axis: int, extent: int):
+    """b = a*(1-y/extent) + b*(y/extent) along `axis` of equal-shaped strided 4-D fp16 views [C,T,H,W]."""
+    _chk(a_view, F16, "a", False), _chk(b_view, F16, "b", False)
+    assert a_view.shape == b_view.shape and a_view.dim() == 4
+    _lib.check(_lib.load().hv_vae_blend_f16(_ptr(a_view), _i64x4(a_view.stride()), _ptr(b_view), _i64x4(b_view.stride()),
+                                            _i32x4(b_view.shape), axis, extent, _stream()), "hv_vae_blend_f16")
+    return b_view
+
+
+def copy4d_(src_view, dst_view):
+    assert src_view.shape == dst_view.shape and src_view.dim() == 4 and src_view.element_size() == 2 and dst_view.element_size() == 2
+    assert src_view.is_cuda and dst_view.is_cuda
+    _lib.check(_lib.load().hv_copy4d_16b(_ptr(src_view), _i64x4(src_view.stride()), _ptr(dst_view), _i64x4(dst_view.stride()),
+                                         _i32x4(dst_view.shape), _stream()), "hv_copy4d_16b")
+    return dst_view
+
+
+def postprocess(x_f16):
+    _chk(x_f16, F16, "x")
+    assert x_f16.is_contiguous()
+    out = torch.empty(x_f16.shape, dtype=torch.float32, device=x_f16.device)
+    _lib.check(_lib.load().hv_vae_postprocess_f16_f32(_ptr(x_f16), _ptr(out), x_f16.numel(), _stream()), "hv_vae_postprocess_f16_f32")
+    return out

@@ -96,6 +96,62 @@ int hv_broadcast_row_bf16(const void* src, void* dst, int64_t n_rows, int D, int
 int hv_copy3d_bf16(const void* src, void* dst, int n_batch, int64_t rows, int cols, int64_t src_batch_stride,
                    int64_t src_ld, int64_t dst_batch_stride, int64_t dst_ld, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * 3D causal VAE decode (hyvideo/vae).  Activations are fp16, CHANNELS-LAST: row = voxel (t*H + h)*W + w, C contiguous.
+ * --------------------------------------------------------------------------------------------------------- */
+
+/* fp16 Linear on MFMA (diffusers Attention to_q/to_k/to_v/to_out of the VAE mid block, unet_causal_3d_blocks.py:579-593;
+ * 1x1x1 convs: post_quant_conv autoencoder_kl_causal_3d.py:115 and conv_shortcut unet_causal_3d_blocks.py:339-347).
+ * out = A.W^T + bias; out_is_f32: fp32 result (attention scores); res (nullable): out = res + f16(y). */
+int hv_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, int M, int N, int K,
+                void* out, int64_t ldo, int out_is_f32, const void* res, int64_t ld_res, hipStream_t stream);
+
+/* K15 (+K17): CausalConv3d 3x3x3 = replicate-pad(W 1,1; H 1,1; T 2,0) + Conv3d (unet_causal_3d_blocks.py:49-75) as an
+ * implicit GEMM; with up_t/up_hw the nearest upsample of UpsampleCausal3D.forward (:154-172: first frame x(1,2,2), others
+ * x(2,2,2)) that precedes its conv is folded into the gather.  x: source [sT,sH,sW,Cin] (row stride ldx);
+ * w_taps: [Cout][27][Cin] fp16 (tap = (dt*3 + dh)*3 + dw); out: [T*H*W, Cout]; res (nullable): out = res + f16(y)
+ * (ResnetBlockCausal3D residual :413-415).  Cin % 64 == 0, Cout % 8 == 0 (callers zero-pad 16->64 and 3->8). */
+int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_taps, const void* bias, void* out, int64_t ldo,
+                         int T, int H, int W, int Cin, int Cout, int up_t, int up_hw, const void* res,
+                         int64_t ld_res, hipStream_t stream);
+
+/* K16 pass 1+2: GroupNorm statistics (nn.GroupNorm(32, C, eps 1e-6, affine), unet_causal_3d_blocks.py:302,323) folded
+ * into a per-channel affine: affine_out[2c] = rstd_g*w[c], affine_out[2c+1] = b[c] - mean_g*rstd_g*w[c].
+ * partial_ws: caller workspace of partial_ws_floats floats (>= 2*C; 2*C*1024 for full parallelism). */
+int hv_groupnorm_affine_f16(const void* x, int64_t ldx, int64_t M, int C, int groups, float eps, const void* weight,
+                            const void* bias, float* partial_ws, int64_t partial_ws_floats, float* affine_out,
+                            hipStream_t stream);
+
+/* K16 pass 3: y = [SiLU](x*affine[2c] + affine[2c+1]) -> fp16 (norm + nonlinearity, unet_causal_3d_blocks.py:361-363,399-405). */
+int hv_groupnorm_apply_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int C, const float* affine,
+                           int silu, hipStream_t stream);
+
+/* K18: P = softmax(scale * S) row-wise, fp32 -> fp16, columns [cols, cols_pad) zero-filled (K padding of the P.V GEMM).
+ * The frame-causal mask of prepare_causal_attention_mask (unet_causal_3d_blocks.py:38-46) is realised by the caller
+ * giving each frame's query rows exactly the key columns of frames <= its own. */
+int hv_softmax_rows_f32_f16(const float* S, int64_t ld_s, void* P, int64_t ld_p, int rows, int cols, int cols_pad,
+                            float scale, hipStream_t stream);
+
+/* [R][C] -> [C][R] for 16-bit elements (V^T for the P.V GEMM). */
+int hv_transpose_16b(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C, hipStream_t stream);
+
+/* latent crop: fp32 z[C,T,H,W] region (element strides) -> channels-last fp16 [T,H,W,Cpad] (zero-padded channels):
+ * the tile slicing of autoencoder_kl_causal_3d.py:443,520 + the fp16 cast of autocast. */
+int hv_vae_latent_tile_f16(const float* z, int64_t sc, int64_t st, int64_t sh, int64_t sw, int C, int T, int H, int W,
+                           int Cpad, void* out, hipStream_t stream);
+
+/* K19: blend_v / blend_h / blend_t (autoencoder_kl_causal_3d.py:344-360) on strided [C,T,H,W] fp16 views:
+ * b[i] = f16(f16(a[i]*(1 - y/extent)) + f16(b[i]*(y/extent))), y = index along `axis`; dims[axis] <= extent. */
+int hv_vae_blend_f16(const void* a, const int64_t* a_strides, void* b, const int64_t* b_strides, const int* dims,
+                     int axis, int extent, hipStream_t stream);
+
+/* crop + concat of tiles (autoencoder_kl_causal_3d.py:463-465,531-537): strided 4-D copy of 16-bit elements. */
+int hv_copy4d_16b(const void* src, const int64_t* src_strides, void* dst, const int64_t* dst_strides, const int* dims,
+                  hipStream_t stream);
+
+/* K20 tail: (image / 2 + 0.5).clamp(0, 1) in fp16 then .float() (pipeline_hunyuan_video.py:1090-1092). */
+int hv_vae_postprocess_f16_f32(const void* x, float* out, int64_t n, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
