@@ -118,6 +118,8 @@ def blend_(a_view, b_view, axis: int, extent: int):
     """b = a*(1-y/extent) + b*(y/extent) along `axis` of equal-shaped strided 4-D fp16 views [C,T,H,W]."""
     _chk(a_view, F16, "a", False), _chk(b_view, F16, "b", False)
     assert a_view.shape == b_view.shape and a_view.dim() == 4
+    if b_view.numel() == 0:
+        return b_view          # empty overlap (e.g. a trailing temporal tile of a single latent frame): nothing to blend
     _lib.check(_lib.load().hv_vae_blend_f16(_ptr(a_view), _i64x4(a_view.stride()), _ptr(b_view), _i64x4(b_view.stride()),
                                             _i32x4(b_view.shape), axis, extent, _stream()), "hv_vae_blend_f16")
     return b_view
@@ -126,6 +128,8 @@ def blend_(a_view, b_view, axis: int, extent: int):
 def copy4d_(src_view, dst_view):
     assert src_view.shape == dst_view.shape and src_view.dim() == 4 and src_view.element_size() == 2 and dst_view.element_size() == 2
     assert src_view.is_cuda and dst_view.is_cuda
+    if dst_view.numel() == 0:
+        return dst_view
     _lib.check(_lib.load().hv_copy4d_16b(_ptr(src_view), _i64x4(src_view.stride()), _ptr(dst_view), _i64x4(dst_view.stride()),
                                          _i32x4(dst_view.shape), _stream()), "hv_copy4d_16b")
     return dst_view
