@@ -30,6 +30,7 @@ SIGNATURES = {
     "hv_masked_mean_bf16": [_p, _p, _p, _i, _i, _p],
     "hv_broadcast_row_bf16": [_p, _p, _l, _i, _l, _p],
     "hv_copy3d_bf16": [_p, _p, _i, _l, _i, _l, _l, _l, _l, _p],
+    "hv_fp8_dequant_bf16": [_p, _p, _p, _l, _p],
     "hv_gemm_f16": [_p, _l, _p, _l, _p, _i, _i, _i, _p, _l, _i, _p, _l, _p],
     "hv_conv3d_causal_f16": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p],
     "hv_groupnorm_affine_f16": [_p, _l, _l, _i, _i, _f, _p, _p, _p, _l, _p, _p],

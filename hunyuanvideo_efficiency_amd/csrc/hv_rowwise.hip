@@ -369,3 +369,39 @@ extern "C" int hv_copy3d_bf16(const void* src, void* dst, int n_batch, int64_t r
                                                                             src_batch_stride, src_ld, dst_batch_stride, dst_ld);
     return hv_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// K14: FP8 weight-only path (fp8_optimization.py:50-53,55-80): W_bf16 = bf16( bf16(w_e4m3fn) * scale_bf16 ).
+// OCP e4m3fn is the native fp8 of gfx950.  HBM-bound: 1 byte in, 2 bytes out, 16 B stores.
+__device__ __forceinline__ float e4m3fn_to_f32(uint32_t b) {
+    const uint32_t s = (b & 0x80u) << 24, e = (b >> 3) & 0xFu, m = b & 7u;
+    float v;
+    if (e == 0) v = (float)m * 0.001953125f;                                   // subnormal: m * 2^-9
+    else if (e == 15 && m == 7) v = __uint_as_float(0x7FC00000u);              // NaN (no infinities in e4m3fn)
+    else v = __uint_as_float(((e + 120u) << 23) | (m << 20));                  // 2^(e-7) * (1 + m/8)
+    return __uint_as_float(__float_as_uint(v) | s);
+}
+
+__global__ __launch_bounds__(256) void fp8_dequant_kernel(const uint8_t* __restrict__ w8, const bf16_t* __restrict__ scale,
+                                                           bf16_t* __restrict__ out, int64_t n) {
+    const float sc = bf2f(scale[0]);
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * blockDim.x * 8) {
+        if (i + 8 <= n) {
+            const u32x2 p = *reinterpret_cast<const u32x2*>(w8 + i);
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = e4m3fn_to_f32((p[j >> 2] >> ((j & 3) * 8)) & 0xFFu) * sc;   // e4m3 -> bf16 is exact
+            *reinterpret_cast<u32x4*>(out + i) = pack8(f);
+        } else {
+            for (int64_t j = i; j < n; ++j) out[j] = f2bf(e4m3fn_to_f32(w8[j]) * sc);
+        }
+    }
+}
+
+extern "C" int hv_fp8_dequant_bf16(const void* w_e4m3fn, const void* scale_bf16, void* out_bf16, int64_t n, hipStream_t stream) {
+    if (!w_e4m3fn || !scale_bf16 || !out_bf16 || n <= 0 || (n & 7)) return HV_ERR_ARG;
+    const int64_t nv = n / 8;
+    const unsigned gx = (unsigned)((nv + 255) / 256 > 16384 ? 16384 : (nv + 255) / 256);
+    fp8_dequant_kernel<<<dim3(gx), dim3(256), 0, stream>>>((const uint8_t*)w_e4m3fn, (const bf16_t*)scale_bf16, (bf16_t*)out_bf16, n);
+    return hv_check_launch();
+}

@@ -1,0 +1,92 @@
+"""HunyuanVideoPipeline: the denoise loop + decode tail of the reference pipeline
+(hyvideo/diffusion/pipelines/pipeline_hunyuan_video.py:664-1100, the part between "prompt embeddings ready" and
+"video tensor on the CPU") on the MI355X kernels.  Text encoding (LLaVA-LLaMA3 + CLIP, :847-886) is outside the hot path:
+the caller passes prompt embeddings (or synthetic ones).  Loop order, dtypes and call surfaces follow the reference:
+set_timesteps -> randn latents -> [transformer -> scheduler.step] x n -> / scaling_factor -> vae.decode -> clamp."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Callable, Optional
+
+import torch
+
+from ... import vae_ops
+
+
+class HunyuanVideoPipeline:
+    def __init__(self, vae, transformer, scheduler, args=None, progress_bar_config=None):
+        self.vae, self.transformer, self.scheduler, self.args = vae, transformer, scheduler, args
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1) if vae is not None else 8
+        self._interrupt = False
+        self._num_timesteps = 0
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, video_length, dtype, device, generator,
+                        latents=None):
+        """pipeline_hunyuan_video.py:558-594: randn [B, C, T, H/8, W/8] * init_noise_sigma (absent for flow matching)."""
+        shape = (batch_size, num_channels_latents, video_length, int(height) // self.vae_scale_factor,
+                 int(width) // self.vae_scale_factor)
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, device=device, dtype=dtype)
+        else:
+            latents = latents.to(device)
+        if hasattr(self.scheduler, "init_noise_sigma"):
+            latents = latents * self.scheduler.init_noise_sigma
+        return latents
+
+    @torch.no_grad()
+    def __call__(self, prompt_embeds: torch.Tensor, prompt_mask: torch.Tensor, prompt_embeds_2: torch.Tensor, height: int,
+                 width: int, video_length: int, num_inference_steps: int = 50, guidance_scale: float = 1.0,
+                 embedded_guidance_scale: Optional[float] = 6.0, generator=None, latents: Optional[torch.Tensor] = None,
+                 freqs_cis=None, output_type: str = "pil", return_dict: bool = True, vae_ver: str = "884-16c-hy",
+                 enable_tiling: bool = True, n_tokens: Optional[int] = None, callback: Optional[Callable] = None,
+                 callback_steps: int = 1):
+        if guidance_scale > 1.0:
+            raise NotImplementedError("classifier-free guidance batch: the shipped model is CFG-distilled (--cfg-scale 1.0)")
+        device = prompt_embeds.device
+        # 4. timesteps (:907-917)
+        self.scheduler.set_timesteps(num_inference_steps, device=device, n_tokens=n_tokens)
+        timesteps = self.scheduler.timesteps
+        # 5. latents (:919-938)
+        if "884" in vae_ver:
+            video_length = (video_length - 1) // 4 + 1
+        elif "888" in vae_ver:
+            video_length = (video_length - 1) // 8 + 1
+        latents = self.prepare_latents(prompt_embeds.shape[0], self.transformer.config.in_channels, height, width, video_length,
+                                       prompt_embeds.dtype, device, generator, latents)
+        self._num_timesteps = len(timesteps)
+        # 7. denoising loop (:955-1045); autocast(bf16) is the kernels' native contract
+        for i, t in enumerate(timesteps):
+            if self.interrupt:
+                continue
+            latent_model_input = self.scheduler.scale_model_input(latents, t)
+            t_expand = t.repeat(latent_model_input.shape[0])
+            guidance_expand = None
+            if embedded_guidance_scale is not None:
+                guidance_expand = torch.tensor([embedded_guidance_scale] * latent_model_input.shape[0], dtype=torch.float32,
+                                               device=device).to(torch.bfloat16) * 1000.0
+            noise_pred = self.transformer(latent_model_input, t_expand, text_states=prompt_embeds, text_mask=prompt_mask,
+                                          text_states_2=prompt_embeds_2, freqs_cos=freqs_cis[0], freqs_sin=freqs_cis[1],
+                                          guidance=guidance_expand, return_dict=True)["x"]
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            if callback is not None and i % callback_steps == 0:
+                callback(i // getattr(self.scheduler, "order", 1), t, latents)
+        # decode tail (:1047-1092)
+        if output_type == "latent":
+            image = latents
+        else:
+            if hasattr(self.vae.config, "shift_factor") and self.vae.config.shift_factor:
+                latents = latents / self.vae.config.scaling_factor + self.vae.config.shift_factor
+            else:
+                latents = latents / self.vae.config.scaling_factor
+            if enable_tiling:
+                self.vae.enable_tiling()
+            image = self.vae.decode(latents, return_dict=False, generator=generator)[0]
+            image = vae_ops.postprocess(image.contiguous())   # (image / 2 + 0.5).clamp(0, 1) in fp16, then fp32
+        image = image.cpu().float()
+        if not return_dict:
+            return image
+        return SimpleNamespace(videos=image)

@@ -25,6 +25,25 @@ class ParamLinear(nn.Module):
         else:
             self.register_parameter("bias", None)
 
+    _fp8_scratch = {}
+
+    def w(self) -> torch.Tensor:
+        """The bf16 weight the GEMM consumes.  For FP8-converted layers (fp8_optimization.convert_fp8_linear) the
+        e4m3fn weight is dequantised per call into one shared scratch buffer, W = bf16(bf16(w8) * fp8_scale), exactly the
+        reference's per-forward dequantisation (fp8_optimization.py:50-53,69-75); launches are stream-ordered, so a
+        single scratch per device is enough and the bf16 copy of the model never exists in HBM."""
+        wt = self.weight
+        if wt.dtype != torch.float8_e4m3fn:
+            return wt
+        key = str(wt.device)
+        buf = ParamLinear._fp8_scratch.get(key)
+        if buf is None or buf.numel() < wt.numel():
+            buf = torch.empty(wt.numel(), dtype=BF16, device=wt.device)
+            ParamLinear._fp8_scratch[key] = buf
+        out = buf[: wt.numel()].view(wt.shape)
+        ops.fp8_dequant(wt, self.fp8_scale, out)
+        return out
+
 
 class ParamNormWeight(nn.Module):
     """RMSNorm gain (norm_layers.py:30-31)."""

@@ -81,12 +81,12 @@ class MMDoubleStreamBlock(nn.Module):
         mods = {}
         for s, lo, hi, n_rope in streams:
             mod = getattr(self, f"{s}_mod")
-            m = ops.linear_smallm(vec, mod.linear.weight, mod.linear.bias, silu_in=True)  # [1, 6d]
+            m = ops.linear_smallm(vec, mod.linear.w(), mod.linear.bias, silu_in=True)  # [1, 6d]
             mods[s] = [m[0, i * d:(i + 1) * d] for i in range(6)]   # shift1, scale1, gate1, shift2, scale2, gate2
             sh1, sc1 = mods[s][0], mods[s][1]
             ops.ln_modulate(ws.x[lo:hi], sh1, sc1, out=ws.xmod[lo:hi])
             qkv_l = getattr(self, f"{s}_attn_qkv")
-            ops.gemm(ws.xmod[lo:hi], qkv_l.weight, qkv_l.bias, out=ws.qkv[lo:hi])
+            ops.gemm(ws.xmod[lo:hi], qkv_l.w(), qkv_l.bias, out=ws.qkv[lo:hi])
             ops.qknorm_rope_(ws.qkv[lo:hi], getattr(self, f"{s}_attn_q_norm").weight,
                              getattr(self, f"{s}_attn_k_norm").weight, cos, sin, n_rope, H, d)
         segment_attention_(self.hybrid_seq_parallel_attn, ws.qkv, ws.cat, s_img, cu1, H, d)
@@ -94,11 +94,11 @@ class MMDoubleStreamBlock(nn.Module):
             _, _, g1, sh2, sc2, g2 = mods[s]
             proj, mlp = getattr(self, f"{s}_attn_proj"), getattr(self, f"{s}_mlp")
             x = ws.x[lo:hi]
-            ops.gemm(ws.cat[lo:hi, :d], proj.weight, proj.bias, out=x, gate=g1, res=x)
+            ops.gemm(ws.cat[lo:hi, :d], proj.w(), proj.bias, out=x, gate=g1, res=x)
             ops.ln_modulate(x, sh2, sc2, out=ws.xmod[lo:hi])
             hbuf = ws.cat[lo:hi, d:]
-            ops.gemm(ws.xmod[lo:hi], mlp.fc1.weight, mlp.fc1.bias, out=hbuf, act=ops.ACT_GELU_TANH)
-            ops.gemm(hbuf, mlp.fc2.weight, mlp.fc2.bias, out=x, gate=g2, res=x)
+            ops.gemm(ws.xmod[lo:hi], mlp.fc1.w(), mlp.fc1.bias, out=hbuf, act=ops.ACT_GELU_TANH)
+            ops.gemm(hbuf, mlp.fc2.w(), mlp.fc2.bias, out=x, gate=g2, res=x)
 
     def forward(self, img, txt, vec, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                 freqs_cis: tuple = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -146,15 +146,15 @@ class MMSingleStreamBlock(nn.Module):
     def run(self, ws: _Workspace, s_img: int, s_txt: int, vec: torch.Tensor, cu1: int,
             cos: Optional[torch.Tensor], sin: Optional[torch.Tensor]):
         d, H = self.hidden_size, self.heads_num
-        m = ops.linear_smallm(vec, self.modulation.linear.weight, self.modulation.linear.bias, silu_in=True)
+        m = ops.linear_smallm(vec, self.modulation.linear.w(), self.modulation.linear.bias, silu_in=True)
         shift, scale, gate = m[0, :d], m[0, d:2 * d], m[0, 2 * d:]
         ops.ln_modulate(ws.x, shift, scale, out=ws.xmod)
         # linear1: cols [0,3d) -> qkv ; cols [3d, 3d+mlp) -> GELU-tanh -> cat[:, d:]   (models.py:339-341,392)
-        ops.gemm(ws.xmod, self.linear1.weight, self.linear1.bias, out=ws.qkv, n_split=3 * d, out1=ws.cat[:, d:],
+        ops.gemm(ws.xmod, self.linear1.w(), self.linear1.bias, out=ws.qkv, n_split=3 * d, out1=ws.cat[:, d:],
                  act1=ops.ACT_GELU_TANH)
         ops.qknorm_rope_(ws.qkv, self.q_norm.weight, self.k_norm.weight, cos, sin, s_img if cos is not None else 0, H, d)
         segment_attention_(self.hybrid_seq_parallel_attn, ws.qkv, ws.cat, s_img, cu1, H, d)
-        ops.gemm(ws.cat, self.linear2.weight, self.linear2.bias, out=ws.x, gate=gate, res=ws.x)
+        ops.gemm(ws.cat, self.linear2.w(), self.linear2.bias, out=ws.x, gate=gate, res=ws.x)
 
     def forward(self, x, vec, txt_len, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                 freqs_cis: Tuple[torch.Tensor, torch.Tensor] = None) -> torch.Tensor:

@@ -206,6 +206,17 @@ def timestep_embedding(t_f32, dim: int = 256, max_period: float = 10000.0):
     return out
 
 
+def fp8_dequant(w8, scale_bf16, out_bf16):
+    """out = bf16(bf16(w8) * scale): w8 float8_e4m3fn (any shape, contiguous), scale a 1-element bf16 tensor."""
+    if not w8.is_cuda or w8.dtype != torch.float8_e4m3fn:
+        raise _lib.HVKernelError("fp8_dequant: expected a float8_e4m3fn GPU tensor")
+    _chk(scale_bf16, BF16, "scale"), _chk(out_bf16, BF16, "out")
+    assert w8.is_contiguous() and out_bf16.is_contiguous() and out_bf16.numel() == w8.numel()
+    _lib.check(_lib.load().hv_fp8_dequant_bf16(_ptr(w8), _ptr(scale_bf16), _ptr(out_bf16), w8.numel(), _stream()),
+               "hv_fp8_dequant_bf16")
+    return out_bf16
+
+
 def copy3d(src, dst, n_batch: int, rows: int, cols: int, src_bs: int, src_ld: int, dst_bs: int, dst_ld: int):
     """dst[b][r][:cols] = src[b][r][:cols] with explicit element strides; src/dst are any bf16 GPU tensors whose
     data_ptr() is element (0,0,0) of the region."""

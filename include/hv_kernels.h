@@ -96,6 +96,11 @@ int hv_broadcast_row_bf16(const void* src, void* dst, int64_t n_rows, int D, int
 int hv_copy3d_bf16(const void* src, void* dst, int n_batch, int64_t rows, int cols, int64_t src_batch_stride,
                    int64_t src_ld, int64_t dst_batch_stride, int64_t dst_ld, hipStream_t stream);
 
+/* K14: FP8 weight-only Linear (modules/fp8_optimization.py:50-53,55-80): out = bf16(bf16(w_e4m3fn[i]) * scale_bf16),
+ * the per-forward dequantisation the reference performs before F.linear; the GEMM then runs on hv_gemm_bf16.
+ * OCP e4m3fn (gfx950-native).  n % 8 == 0. */
+int hv_fp8_dequant_bf16(const void* w_e4m3fn, const void* scale_bf16, void* out_bf16, int64_t n, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * 3D causal VAE decode (hyvideo/vae).  Activations are fp16, CHANNELS-LAST: row = voxel (t*H + h)*W + w, C contiguous.
  * --------------------------------------------------------------------------------------------------------- */

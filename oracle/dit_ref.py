@@ -352,3 +352,29 @@ def denoise_loop(sd, cfg, latents: Tensor, n_steps: int, text_states, text_mask,
         preds.append(v)
         latents = euler_step(latents, v, sig, i)
     return latents, preds
+
+
+# ----------------------------------------------------------------------------- FP8 weight-only path
+def fp8_maxval() -> float:
+    """modules/fp8_optimization.py:7-18 (e4m3: 1.75 * 2^8)."""
+    return 448.0
+
+
+def fp8_quant_dequant(w: Tensor, scale: Tensor) -> Tensor:
+    """fp8_tensor_quant + quantize_to_fp8 (modules/fp8_optimization.py:20-48): W/scale clamped to +-448 and rounded on the
+    e4m3 grid (3 mantissa bits, exponent bias 7, minimum exponent step 2^-9)."""
+    x = (w / scale).clamp(-448.0, 448.0)
+    log_scales = torch.clamp(torch.floor(torch.log2(torch.abs(x)) + 7), min=1.0)
+    step = 2.0 ** (log_scales - 3 - 7)
+    return torch.round(x / step) * step
+
+
+def fp8_linear(x: Tensor, w: Tensor, b: Optional[Tensor], original_dtype=torch.float32,
+               scale: Optional[Tensor] = None) -> Tensor:
+    """fp8_linear_forward (modules/fp8_optimization.py:55-80): weight quantised (on the fly: scale = max|W|/448), stored as
+    e4m3fn, dequantised as w8.type(dtype) * scale.to(dtype), then F.linear in `original_dtype`."""
+    if scale is None:
+        scale = torch.max(torch.abs(w.flatten())) / fp8_maxval()
+    w8 = fp8_quant_dequant(w, scale).to(torch.float8_e4m3fn)
+    wd = w8.to(original_dtype) * scale.to(original_dtype)
+    return F.linear(x.to(original_dtype), wd, None if b is None else b.to(original_dtype))

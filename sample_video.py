@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""sample_video.py with the reference's flag names (sample_video.py:12-55, hyvideo/config.py) for the hot path on
+MI355X.  There are no checkpoints or text encoders in this environment, so weights are random-init (deterministic
+hash) and prompt embeddings are synthetic; with real weights, load state dicts into the same modules
+(state-dict key names are the reference's).  torchrun --nproc_per_node=8 sample_video.py --ulysses-degree 8 ...
+shards the token axis exactly like the reference."""
+import argparse
+import os
+import time
+
+import torch
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description="HunyuanVideo denoise + decode on MI355X kernels")
+    p.add_argument("--model", default="HYVideo-T/2-cfgdistill")
+    p.add_argument("--precision", default="bf16", choices=["bf16"])
+    p.add_argument("--rope-theta", type=int, default=256)
+    p.add_argument("--vae", default="884-16c-hy")
+    p.add_argument("--vae-precision", default="fp16", choices=["fp16"])
+    p.add_argument("--vae-tiling", action="store_true", default=True)
+    p.add_argument("--flow-shift", type=float, default=7.0)
+    p.add_argument("--flow-reverse", action="store_true", default=True)
+    p.add_argument("--flow-solver", default="euler")
+    p.add_argument("--infer-steps", type=int, default=50)
+    p.add_argument("--video-size", type=int, nargs="+", default=[720, 1280])
+    p.add_argument("--video-length", type=int, default=129)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--cfg-scale", type=float, default=1.0)
+    p.add_argument("--embedded-cfg-scale", type=float, default=6.0)
+    p.add_argument("--use-fp8", action="store_true")
+    p.add_argument("--ulysses-degree", type=int, default=1)
+    p.add_argument("--ring-degree", type=int, default=1)
+    p.add_argument("--text-len", type=int, default=256)
+    p.add_argument("--tiny", action="store_true", help="tiny DiT (d=256, 1+1 blocks) and reduced VAE: plumbing check")
+    p.add_argument("--save-path", default="./results")
+    return p.parse_args()
+
+
+def main():
+    a = parse_args()
+    from hunyuanvideo_efficiency_amd import synthetic as syn
+    from hunyuanvideo_efficiency_amd.inference import init_distributed, parallelize_transformer, get_rotary_pos_embed
+    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.vae import AutoencoderKLCausal3D
+    from hunyuanvideo_efficiency_amd.diffusion.schedulers import FlowMatchDiscreteScheduler
+    from hunyuanvideo_efficiency_amd.diffusion.pipelines import HunyuanVideoPipeline
+    from hunyuanvideo_efficiency_amd.modules.fp8_optimization import convert_fp8_linear
+    dev = init_distributed(a.ulysses_degree, a.ring_degree)
+    rank = int(os.environ.get("RANK", "0"))
+    h, w = (a.video_size * 2)[:2]
+    if h % 16 or w % 16 or (a.video_length - 1) % 4:
+        raise ValueError("height/width must be multiples of 16 and (video_length - 1) a multiple of 4 (inference.py:571-586)")
+    cfg = syn.tiny_config() if a.tiny else syn.DiTConfig()
+    model = build_model(cfg, dev, seed=0)
+    if a.use_fp8:
+        convert_fp8_linear(model, None, torch.bfloat16)
+    boc = (64, 64, 128, 128) if a.tiny else syn.VAE_BLOCK_OUT_CHANNELS
+    vae = AutoencoderKLCausal3D(block_out_channels=boc, device=dev)
+    with torch.no_grad():
+        for k, p in vae.state_dict().items():
+            p.copy_(syn.synth_param("vae." + k, tuple(p.shape), 0, dev).to(p.dtype))
+    sched = FlowMatchDiscreteScheduler(shift=a.flow_shift, reverse=a.flow_reverse, solver=a.flow_solver)
+    pipe = HunyuanVideoPipeline(vae, model, sched, a)
+    if a.ulysses_degree > 1:
+        parallelize_transformer(pipe)
+    lt = (a.video_length - 1) // 4 + 1
+    _, ts, tm, ts2 = syn.synth_dit_inputs(cfg, (lt, h // 8, w // 8), a.text_len, 11, seed=a.seed, device=dev)
+    freqs = get_rotary_pos_embed(model, a.video_length, h, w, a.vae, a.rope_theta, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(a.seed)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out = pipe(ts.to(torch.float16), tm, ts2.to(torch.float16), h, w, a.video_length, num_inference_steps=a.infer_steps,
+               guidance_scale=a.cfg_scale, embedded_guidance_scale=a.embedded_cfg_scale, generator=gen, freqs_cis=freqs,
+               vae_ver=a.vae, enable_tiling=a.vae_tiling, n_tokens=freqs[0].shape[0])
+    dt = time.time() - t0
+    if rank == 0:
+        v = out.videos
+        print(f"Success, time: {dt:.2f} s; video tensor {tuple(v.shape)} {v.dtype} range [{float(v.min()):.3f}, {float(v.max()):.3f}]")
+        os.makedirs(a.save_path, exist_ok=True)
+        torch.save(v[:, :, :1].clone(), os.path.join(a.save_path, "first_frame.pt"))
+
+
+if __name__ == "__main__":
+    main()

@@ -139,3 +139,41 @@ def test_sequence_parallel_path_single_rank_rccl(tiny, golden):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_fp8_weight_path(tiny, golden):
+    """K14: hv_fp8_dequant_bf16 on all 256 e4m3fn codes; then convert_fp8_linear on the tiny model: forward with FP8
+    weights == oracle forward with the dequantised bf16 weights (the reference's semantics: weight-only FP8)."""
+    from hunyuanvideo_efficiency_amd import ops
+    from hunyuanvideo_efficiency_amd.modules.fp8_optimization import convert_fp8_linear
+    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
+    codes = torch.arange(256, dtype=torch.uint8).repeat(4).to(DEV).view(torch.float8_e4m3fn)
+    scale = torch.tensor([0.01171875], dtype=torch.bfloat16, device=DEV)
+    out = torch.empty(1024, dtype=torch.bfloat16, device=DEV)
+    ops.fp8_dequant(codes, scale, out)
+    ref = (codes.cpu().to(torch.bfloat16) * scale.cpu())
+    got, ref = out.cpu().float(), ref.float()
+    nan = torch.isnan(ref)
+    assert torch.equal(torch.isnan(got), nan) and torch.equal(got[~nan], ref[~nan])
+
+    cfg, _ = tiny
+    model = build_model(cfg, DEV)
+    n = convert_fp8_linear(model, None, torch.bfloat16)
+    assert n == 2 * 6 + 3 and model.double_blocks[0].img_attn_qkv.weight.dtype == torch.float8_e4m3fn
+    sd = {}
+    for k, p in model.state_dict().items():
+        sd[k] = p.float().cpu()
+    for name, layer in model.named_modules():
+        if hasattr(layer, "fp8_scale"):
+            sd[name + ".weight"] = (layer.weight.cpu().to(torch.bfloat16) * layer.fp8_scale.cpu()).float()
+    g = golden("dit_tiny_forward")
+    T, H, W = g["latent_thw"].tolist()
+    cos, sin = get_nd_rotary_pos_embed(cfg.rope_dim_list, [T, H // 2, W // 2], theta=256, use_real=True, device=DEV)
+    with torch.no_grad():
+        out = model(g["x"].to(DEV), g["t"].to(DEV), text_states=g["text_states"].to(DEV), text_mask=g["text_mask"].to(DEV),
+                    text_states_2=g["text_states_2"].to(DEV), freqs_cos=cos, freqs_sin=sin, guidance=g["guidance"].to(DEV))["x"]
+    ref = R.dit_forward(sd, cfg, g["x"], g["t"], E.r(g["text_states"]), g["text_mask"], g["text_states_2"], cos.cpu(), sin.cpu(),
+                        g["guidance"], E)
+    assert rel(out, ref) < 3e-2
+    assert rel(out, g["out"]) < 0.2     # FP8 weights move the output (3-bit mantissa), but it stays the same function

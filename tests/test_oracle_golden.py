@@ -141,3 +141,19 @@ def test_bf16_emulation_stays_near_fp32(golden):
                         g["guidance"], R.Prec(True))
     err = (out - g["out"]).abs().max() / g["out"].abs().max()
     assert err < 3e-2, float(err)
+
+
+def test_fp8_weight_path(golden):
+    """fp8_optimization.py: scale, e4m3fn bits, dequantised weight and Linear output of the reference vs the oracle and the
+    host-side quantiser of the package."""
+    g = golden("dit_fp8")
+    assert float(g["maxval"]) == R.fp8_maxval() == 448.0
+    scale = torch.max(torch.abs(g["w"].flatten())) / 448.0
+    close(scale, g["scale"], rtol=0, atol=0)
+    w8 = R.fp8_quant_dequant(g["w"], scale).to(torch.float8_e4m3fn)
+    assert torch.equal(w8.view(torch.uint8), g["w8_bits"])
+    close(w8.float() * scale, g["w_dequant"], rtol=0, atol=0)
+    close(R.fp8_linear(g["x"], g["w"], g["b"]), g["y_fly"], rtol=1e-5, atol=1e-5)
+    from hunyuanvideo_efficiency_amd.modules import fp8_optimization as F8
+    q8, s = F8.quantize_weight(g["w"])
+    assert torch.equal(q8.view(torch.uint8), g["w8_bits"]) and float(s) == float(g["scale"]) and F8.get_fp_maxval() == 448.0
