@@ -235,7 +235,7 @@ class HYVideoDiffusionTransformer(nn.Module):
 
     @property
     def dtype(self):
-        return self.double_blocks[0].img_attn_qkv.weight.dtype if len(self.double_blocks) else self.img_in.proj.weight.dtype
+        return self.img_in.proj.weight.dtype   # (block Linears may hold float8_e4m3fn after convert_fp8_linear)
 
     def enable_deterministic(self):
         for b in list(self.double_blocks) + list(self.single_blocks):

@@ -160,7 +160,7 @@ def test_fp8_weight_path(tiny, golden):
     cfg, _ = tiny
     model = build_model(cfg, DEV)
     n = convert_fp8_linear(model, None, torch.bfloat16)
-    assert n == 2 * 6 + 3 and model.double_blocks[0].img_attn_qkv.weight.dtype == torch.float8_e4m3fn
+    assert n == 2 * 5 + 3 and model.double_blocks[0].img_attn_qkv.weight.dtype == torch.float8_e4m3fn
     sd = {}
     for k, p in model.state_dict().items():
         sd[k] = p.float().cpu()
