@@ -10,13 +10,17 @@
 //     operand of the next MFMA (k = key); V^T fragments come from the row-major V tile in LDS through
 //     ds_read_b64_tr_b16 (hardware transpose).  O^T keeps the query on the lane too, so the online-softmax
 //     rescale is a per-lane scalar multiply and is skipped (wave-uniformly) when no row max moved.
-//   * K and V tiles are staged HBM -> VGPR -> LDS (loads issued one tile ahead, written after the
-//     barrier), double buffered; K rows are XOR-swizzled by key for conflict-free ds_read_b128, V rows are
-//     swizzled in 64-byte quarters for conflict-free transposed reads.
+//   * K and V tiles arrive by LDS-DMA (global_load_lds_dwordx4; the bank swizzle is applied on the per-lane
+//     SOURCE address so the LDS image stays lane-linear): K two tiles ahead, V one tile ahead, 2-deep rings;
+//     K rows are XOR-swizzled by key for conflict-free ds_read_b128, V rows in 64-byte quarters for
+//     conflict-free transposed reads (rocprofv3: SQ_LDS_BANK_CONFLICT = 0).
+//   * software pipeline across KV tiles inside each wave: S(t+1) = K(t+1).Q^T is issued while the softmax of
+//     tile t runs on the VALU, then O^T += V(t)^T.P(t)^T; one workgroup barrier per tile.
 // Workgroups are ordered head-major so co-resident workgroups stream the same head's K/V (L2 / MALL reuse).
 // Algorithmic work: 4 * n_q * n_kv * 128 flop per head.
 #include "hv_common.hpp"
 #include "../../include/hv_kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -48,15 +52,27 @@ __device__ __forceinline__ float half_swap_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// =====================================================================================================================
+// v2: software-pipelined across KV tiles inside each wave so that MFMA and VALU work of DIFFERENT tiles are adjacent in
+// the instruction stream (the two co-resident waves of a SIMD run the same program in lockstep behind one barrier per
+// tile, so without this the matrix pipe idles during every softmax):
+//   stage 1:  S(t+1) = K(t+1).Q^T  (16 MFMA)   ||  row max of S(t), rescale check, exp of key block 0 of S(t)
+//   stage 2:  O^T += V(t)[kb0]^T.P(t)[kb0] (8 MFMA)  ||  exp of key block 1 of S(t)
+//   stage 3:  O^T += V(t)[kb1]^T.P(t)[kb1] (8 MFMA)
+// K and V tiles arrive by LDS-DMA (global_load_lds_dwordx4, swizzle applied on the per-lane SOURCE address; no staging
+// VGPRs): K two tiles ahead, V one tile ahead, each into a 2-deep ring; one barrier per tile.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v2(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | V0 | V1], 16 KiB each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int head = blockIdx.x / a.n_qtiles;
     const int qt = blockIdx.x % a.n_qtiles;
     const int q0 = qt * QTILE + wave * QROWS_WAVE;
+    constexpr int KOFF = 0, VOFF = 2 * KV_TILE_BYTES;
 
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0+lr][16*ks + 8*lh .. +8]
     bf16x8 qf[8];
     {
         const int qrow = min(q0 + lr, a.n_q - 1);
@@ -65,51 +81,46 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
     }
 
-    // ---- staging: thread -> (key = i*32 + tid/16, chunk = tid%16) for i = 0,1 ; K and V
-    const int skey = tid >> 4, sch = tid & 15;
-    const bf16_t* kbase = a.k + head * D + sch * 8;
-    const bf16_t* vbase = a.v + head * D + sch * 8;
-    int k_lds[2], v_lds[2];
+    // ---- DMA addressing: wave w owns keys [8w, 8w+8) of a tile; piece i (0,1): key = 8w + 4i + (lane>>4), LDS chunk pos = lane&15
+    const int dkey0 = 8 * wave + (lane >> 4), dcp = lane & 15;
+    const bf16_t* kcol[2];
+    const bf16_t* vcol[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int key = i * 32 + skey;
-        k_lds[i] = key * 256 + ((sch ^ (key & 15)) << 4);
-        v_lds[i] = KV_TILE_BYTES + key * 256 + ((sch ^ ((key & 3) << 2)) << 4);
+        const int key = dkey0 + 4 * i;
+        kcol[i] = a.k + head * D + ((dcp ^ (key & 15)) << 3);
+        vcol[i] = a.v + head * D + ((dcp ^ ((key & 3) << 2)) << 3);
     }
-    u32x4 kreg[2], vreg[2];
-    auto load_tile = [&](int tile) {
+    const int wave_lds = wave * 2048;   // 8 keys x 256 B
+    auto dma_k = [&](int tile, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int key = min(tile * KVT + i * 32 + skey, a.n_kv - 1);
-            kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)key * a.sk);
-            vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)key * a.sv);
+            const int key = min(tile * KVT + dkey0 + 4 * i, a.n_kv - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(kcol[i] + (int64_t)key * a.sk),
+                                             (lds_void_ptr)(smem + KOFF + buf * KV_TILE_BYTES + wave_lds + i * 1024), 16, 0, 0);
         }
     };
-    auto write_tile = [&](int buf) {
-        char* b = smem + buf * BUF_BYTES;
+    auto dma_v = [&](int tile, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<u32x4*>(b + k_lds[i]) = kreg[i];
-            *reinterpret_cast<u32x4*>(b + v_lds[i]) = vreg[i];
+            const int key = min(tile * KVT + dkey0 + 4 * i, a.n_kv - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(vcol[i] + (int64_t)key * a.sv),
+                                             (lds_void_ptr)(smem + VOFF + buf * KV_TILE_BYTES + wave_lds + i * 1024), 16, 0, 0);
         }
     };
 
-    // ---- read offsets
-    // K (A operand): key = kb*32 + lr, chunk = 2*ks + lh  ->  key*256 + ((chunk ^ (key&15)) << 4)
     int kread[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         const int key = kb * 32 + lr;
-        kread[kb] = key * 256 + ((lh ^ (key & 15)) << 4);   // ks folded in by XOR of (2*ks)<<4 below
+        kread[kb] = key * 256 + ((lh ^ (key & 15)) << 4);
     }
-    // V^T (A operand of O^T += V^T.P^T) via transposed reads: 16-lane group G = lane>>4, i = lane&15,
-    // q = i>>2 (row of the 4x16 block), p = i&3.  Block rows: keys key0 + q, cols d0 + 4p.. ; d0 = db*32 + (G&1)*16.
     const int vq = (lane & 15) >> 2, vp = lane & 3, vG = lane >> 4;
-    int vread;  // byte offset for (kb=0, s=0, half-block 0, db=0); others are added/XORed below
+    int vread;
     {
-        const int key = 4 * (vG >> 1) + vq;              // key0 = 4*lh (+ kb*32 + 16*s + 8*second)
-        const int chunk16 = ((vG & 1) * 16 + 4 * vp) >> 3; // + db*4
-        vread = KV_TILE_BYTES + key * 256 + ((chunk16 ^ ((key & 3) << 2)) << 4) + (vp & 1) * 8;
+        const int key = 4 * (vG >> 1) + vq;
+        const int chunk16 = ((vG & 1) * 16 + 4 * vp) >> 3;
+        vread = key * 256 + ((chunk16 ^ ((key & 3) << 2)) << 4) + (vp & 1) * 8;
     }
 
     f32x16 oT[4];
@@ -119,47 +130,70 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) oT[db][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
     const float c = a.scale_log2e;
-
     const int ntiles = (a.n_kv + KVT - 1) / KVT;
-    load_tile(0);
-    write_tile(0);
-    __syncthreads();
-    if (ntiles > 1) load_tile(1);
 
-    for (int t = 0; t < ntiles; ++t) {
-        const char* buf = smem + (t & 1) * BUF_BYTES;
-        // ---------------- S^T = K . Q^T   (2 key blocks x 8 k-steps)
-        f32x16 sT[2];
+    auto qk = [&](f32x16 (&S)[2], int buf) {
+        const char* kb_ = smem + KOFF + buf * KV_TILE_BYTES;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sT[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) S[kb][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf + (kread[kb] ^ (ks << 5)));
-                sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sT[kb], 0, 0, 0);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_ + (kread[kb] ^ (ks << 5)));
+                S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[kb], 0, 0, 0);
             }
         }
-        // ---------------- tail mask (last tile only): key = t*64 + kb*32 + (r&3) + 8*(r>>2) + 4*lh
-        if (t == ntiles - 1 && (a.n_kv & (KVT - 1))) {
+    };
+    auto exp_block = [&](const f32x16& S, bf16x8 (&pf)[2], float& ls) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[8 * s + j], c, -m_run));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[8 * s + j + 1], c, -m_run));
+                ls += p0 + p1;
+                w[j >> 1] = pack_bf2(p0, p1);
+            }
+            pf[s] = __builtin_bit_cast(bf16x8, w);
+        }
+    };
+    auto pv_block = [&](const bf16x8 (&pf)[2], int kb, int buf) {
+        const char* vb_ = smem + VOFF + buf * KV_TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int koff = (kb * 32 + 16 * s) * 256;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const char* p0 = vb_ + ((vread + koff) ^ (db << 6));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * 256));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oT[db], 0, 0, 0);
+            }
+        }
+    };
+    // row max of S(t) (+ tail mask on the last tile) and the rare rescale; ends in a wave-uniform branch
+    auto softmax_head = [&](f32x16 (&Sc)[2], int t, bool last) {
+        if (last && (a.n_kv & (KVT - 1))) {
             const int kbase_i = t * KVT + 4 * lh;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kbase_i + kb * 32 + (r & 3) + 8 * (r >> 2);
-                    if (key >= a.n_kv) sT[kb][r] = -INFINITY;
+                    if (key >= a.n_kv) Sc[kb][r] = -INFINITY;
                 }
         }
-        // ---------------- online softmax (query = lane&31; this lane holds 32 of the tile's 64 keys)
-        float mx = sT[0][0];
+        float mx = Sc[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sT[0][r]);
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, Sc[0][r]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[1][r]);
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, Sc[1][r]);
         mx = half_swap_max(mx) * c;
         const float m_new = fmaxf(m_run, mx);
-        if (__any(m_new > m_run)) {   // wave-uniform: rescale only when some row's max moved
+        if (__any(m_new > m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
 #pragma unroll
@@ -168,48 +202,53 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) oT[db][r] *= alpha;
             m_run = m_new;
         }
-        bf16x8 pf[2][2];
+    };
+    // steady-state iteration (branch-free after the rescale check, so the scheduler can interleave MFMA and VALU):
+    // consumes Sc = S(t), produces Sn = S(t+1)
+    auto body_main = [&](f32x16 (&Sc)[2], f32x16 (&Sn)[2], int t) {
+        if (t + 2 < ntiles) dma_k(t + 2, t & 1);
+        dma_v(t + 1, (t + 1) & 1);
+        softmax_head(Sc, t, false);
+        bf16x8 p0[2], p1[2];
         float ls = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                u32x4 w;
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[kb][8 * s + j], c, -m_run));
-                    const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[kb][8 * s + j + 1], c, -m_run));
-                    ls += p0 + p1;
-                    w[j >> 1] = pack_bf2(p0, p1);
-                }
-                pf[kb][s] = __builtin_bit_cast(bf16x8, w);   // (whole-vector cast: element-wise __bf16 inserts miscompile)
-            }
+        qk(Sn, (t + 1) & 1);            // stage 1: 16 MFMA  ||  exp of key block 0
+        exp_block(Sc[0], p0, ls);
+        pv_block(p0, 0, t & 1);         // stage 2: 8 MFMA   ||  exp of key block 1
+        exp_block(Sc[1], p1, ls);
+        pv_block(p1, 1, t & 1);         // stage 3: 8 MFMA
         l_run += ls;
-        // ---------------- O^T += V^T . P^T   (4 d-blocks x 4 k-steps of 16 keys)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int koff = (kb * 32 + 16 * s) * 256;
-#pragma unroll
-                for (int db = 0; db < 4; ++db) {
-                    // chunk16 += db*4 (bits 2-3 of the chunk index; the swizzle XORs the same bits) -> XOR (db<<6)
-                    const char* p0 = buf + ((vread + koff) ^ (db << 6));
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * 256));
-                    const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                    oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], oT[db], 0, 0, 0);
-                }
-            }
-        // ---------------- rotate buffers: tile t+1 (in registers since the last barrier) -> LDS
-        if (t + 1 < ntiles) {
-            write_tile((t + 1) & 1);
-            __syncthreads();
-            if (t + 2 < ntiles) load_tile(t + 2);
-        }
+        __syncthreads();
+    };
+    auto body_last = [&](f32x16 (&Sc)[2], int t) {
+        softmax_head(Sc, t, true);
+        bf16x8 p0[2], p1[2];
+        float ls = 0.f;
+        exp_block(Sc[0], p0, ls);
+        pv_block(p0, 0, t & 1);
+        exp_block(Sc[1], p1, ls);
+        pv_block(p1, 1, t & 1);
+        l_run += ls;
+    };
+
+    f32x16 sA[2], sB[2];
+    dma_k(0, 0);
+    dma_v(0, 0);
+    if (ntiles > 1) dma_k(1, 1);
+    __syncthreads();
+    qk(sA, 0);
+    __syncthreads();   // every wave finished reading K[0] before tile 2 is DMA'd over it
+    int t = 0;
+    for (; t + 2 < ntiles; t += 2) {
+        body_main(sA, sB, t);
+        body_main(sB, sA, t + 1);
+    }
+    if (t + 1 < ntiles) {
+        body_main(sA, sB, t);
+        body_last(sB, t + 1);
+    } else {
+        body_last(sA, t);
     }
 
-    // ---------------- epilogue: O[q][d] = O^T / l ; lane (q = lr, lh) holds d = db*32 + (r&3) + 8*(r>>2) + 4*lh
     const float l_tot = half_swap_sum(l_run);
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + lr;
@@ -245,10 +284,10 @@ extern "C" int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.scale_log2e = scale * 1.4426950408889634f;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn_fwd_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
             return HV_ERR_LAUNCH;
         attr_set = true;
     }
-    attn_fwd_kernel<<<dim3((unsigned)(a.n_qtiles * n_heads)), dim3(512), ATT_LDS, stream>>>(a);
+    attn_fwd_kernel_v2<<<dim3((unsigned)(a.n_qtiles * n_heads)), dim3(512), ATT_LDS, stream>>>(a);
     return hv_check_launch();
 }
