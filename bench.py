@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="720p129f", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-by-`value`) VAE tiled decode of the same video")
     a = ap.parse_args()
 
     import torch
@@ -141,6 +142,24 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
+    # end-to-end leg (reported beside `value`, never part of it): VAE tiled decode of this video's latents on rank 0's GPU
+    vae_s = None
+    if not tiny and not a.no_vae and rank == 0:
+        from hunyuanvideo_efficiency_amd.vae import AutoencoderKLCausal3D
+        vae = AutoencoderKLCausal3D(device=dev)
+        with torch.no_grad():
+            for k, p in vae.state_dict().items():
+                p.copy_(syn.synth_param("vae." + k, tuple(p.shape), 0, dev).to(p.dtype))
+        vae.enable_tiling()
+        z = syn.hashed_uniform((1, 16, T, H, W), "vae.z", 0, dev) * 1.7
+        vae.decode(z[:, :, :5, :32, :32], return_dict=False)           # warm-up (weight re-layout, kernel load)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img = vae.decode(z, return_dict=False)[0]
+        torch.cuda.synchronize()
+        vae_s = time.perf_counter() - t0
+        assert bool(torch.isfinite(img).all())
+        del vae, img, z
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -159,6 +178,14 @@ def main():
         avg_ms = sum(att_ms) / max(len(att_ms), 1)
         avg_flop = sum(att_flop) / max(len(att_flop), 1)
         achieved = avg_flop / (avg_ms * 1e-3) / 1e12 if att_ms else 0.0
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (same kernel, same shape; FETCH_SIZE x2 gfx950 correction)
+        traffic, traffic_note = None, None
+        tf = os.path.join(ROOT, "profiles", "r01", "attn_traffic.json")
+        if world == 1 and a.workload == "720p129f" and os.path.exists(tf):
+            tj = json.load(open(tf))
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_note = ("bytes/launch from profiles/r01/attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes); "
+                            f"algorithmic {tj['algorithmic_bytes_per_launch']:.3e} B; counter includes Infinity-Cache hits (per-XCD K/V re-streams)")
         out = {
             "metric": "denoise-steps/sec (720x1280x129f, HunyuanVideo DiT 20+40 blocks, bf16)" if not tiny else "denoise-steps/sec (tiny)",
             "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -168,11 +195,13 @@ def main():
                                    f"d={cfg.hidden_size}, heads={cfg.heads_num}, {cfg.mm_double_blocks_depth}+{cfg.mm_single_blocks_depth} blocks",
                        "parallelism": "single GPU" if world == 1 else f"ulysses{world} (token-axis shard, RCCL all-to-all)"},
             "sec_per_video_50steps_denoise_only": 50 * ms_per_step / 1e3,
+            "vae_tiled_decode_s": vae_s,
+            "sec_per_video_50steps_plus_vae_decode": (50 * ms_per_step / 1e3 + vae_s) if vae_s is not None else None,
             "step_pflop": f_step / 1e15,
             "step_mfma_frac": f_step / (ms_per_step * 1e-3) / (world * PEAK_BF16_TFLOPS * 1e12),
             "roofline": {"kernel": "attn_fwd_kernel (hv_attn_fwd_bf16, main segment)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "launches": len(att_ms), "avg_launch_ms": avg_ms, "flop_per_launch": avg_flop},
         }
         if world == 1 and not a.no_cpu_baseline:
