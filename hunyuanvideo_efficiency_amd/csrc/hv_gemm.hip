@@ -24,10 +24,10 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffered: 128 KiB
+constexpr int BM = 256, BK = 64;                 // BN is a template parameter: 256 (default) or 128 (N <= 128: VAE 128-channel convs)
+constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB per A tile (W tile: BN * BK * 2)
+template <int BN> constexpr int stage_bytes() { return TILE_BYTES + BN * BK * 2; }
+template <int BN> constexpr int lds_bytes() { return 2 * stage_bytes<BN>(); }   // double buffered: 128 KiB (BN=256) / 96 KiB (BN=128)
 constexpr int GROUP_M = 4;
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -79,8 +79,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-template <typename DT, bool CONV>
+template <typename DT, bool CONV, int BN>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
+    constexpr int STAGE_BYTES = stage_bytes<BN>();
+    constexpr int NREP = BN / 64;              // n-repeats of 16 per wave (4 waves along N)
+    constexpr int WPIECES = BN / 64;           // 64-row DMA pieces of the W tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -103,12 +106,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     // ---- per-thread staging addresses: 4 DMA pieces per operand per K-tile, each 512 thr x 16 B = 64 rows
     const int srow = tid >> 3, scp = tid & 7;  // row within a 64-row piece, 16-B chunk position in LDS
     const uint16_t* a_src[4];
-    const uint16_t* w_src[4];
+    const uint16_t* w_src[WPIECES];
     int vt[4], vh[4], vw[4];   // conv: output voxel of each staged row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = i * 64 + srow;
-        const int ar = min(m0 + row, g.M - 1), wr = min(n0 + row, g.N - 1);  // clamp: tails read valid rows
+        const int ar = min(m0 + row, g.M - 1);  // clamp: tails read valid rows
         if (CONV) {
             vw[i] = ar % g.cW;
             const int th = ar / g.cW;
@@ -118,6 +121,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         } else {
             a_src[i] = g.A + (int64_t)ar * g.lda + ((scp ^ swz_a(row)) << 3);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < WPIECES; ++i) {
+        const int row = i * 64 + srow;
+        const int wr = min(n0 + row, g.N - 1);
         w_src[i] = g.W + (int64_t)wr * g.ldw + ((scp ^ swz_w(row)) << 3);
     }
     const int wave_lds = wave * 1024;  // wave-uniform base of this wave's 1 KiB slice of each piece
@@ -145,30 +153,30 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + koff), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WPIECES; ++i)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + koff), (lds_ptr_t)(base + TILE_BYTES + i * 8192), 16, 0, 0);
     };
 
     // ---- fragment read offsets (bytes inside an operand tile), k-step 0; k-step 1 flips chunk bit 2
     const int fr = lane & 15, fq = lane >> 4;
-    int a_off[8], w_off[4];
+    int a_off[8], w_off[NREP];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int row = wm * 128 + mi * 16 + fr;
         a_off[mi] = row * 128 + ((fq ^ swz_a(row)) << 4);
     }
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NREP; ++ni) {
         // MFMA row i of n-repeat ni holds W row: (ni>>1)*32 + (i>>2)*8 + (ni&1)*4 + (i&3)
-        const int row = wn * 64 + (ni >> 1) * 32 + (fr >> 2) * 8 + (ni & 1) * 4 + (fr & 3);
+        const int row = wn * (BN / 4) + (ni >> 1) * 32 + (fr >> 2) * 8 + (ni & 1) * 4 + (fr & 3);
         w_off[ni] = row * 128 + ((fq ^ swz_w(row)) << 4);
     }
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][NREP];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < NREP; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkt = g.K / BK;
     stage(0, 0);
@@ -182,15 +190,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         const char* Wt = At + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            vec8 af[8], wf[4];
+            vec8 af[8], wf[NREP];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wf[ni] = *reinterpret_cast<const vec8*>(Wt + (w_off[ni] ^ (ks << 6)));
+            for (int ni = 0; ni < NREP; ++ni) wf[ni] = *reinterpret_cast<const vec8*>(Wt + (w_off[ni] ^ (ks << 6)));
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const vec8*>(At + (a_off[mi] ^ (ks << 6)));
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = DT::mfma(wf[ni], af[mi], acc[mi][ni]);
+                for (int ni = 0; ni < NREP; ++ni) acc[mi][ni] = DT::mfma(wf[ni], af[mi], acc[mi][ni]);
         }
         __syncthreads();
     }
@@ -205,8 +213,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     };
     const int mrow0 = m0 + wm * 128 + fr;
 #pragma unroll
-    for (int np = 0; np < 2; ++np) {
-        const int n = n0 + wn * 64 + np * 32 + fq * 8;
+    for (int np = 0; np < NREP / 2; ++np) {
+        const int n = n0 + wn * (BN / 4) + np * 32 + fq * 8;
         if (n >= g.N) continue;
         float b[8], gt[8];
         if (g.bias) unpack(*reinterpret_cast<const u32x4*>(g.bias + n), b);
@@ -258,18 +266,25 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
-template <typename DT, bool CONV>
-int launch(GemmArgs& g, hipStream_t stream) {
+template <typename DT, bool CONV, int BN>
+int launch_bn(GemmArgs& g, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_kernel<DT, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm_kernel<DT, CONV, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<BN>()) != hipSuccess)
             return HV_ERR_LAUNCH;
         attr_set = true;
     }
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    gemm_kernel<DT, CONV><<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS_BYTES, stream>>>(g);
+    gemm_kernel<DT, CONV, BN><<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), lds_bytes<BN>(), stream>>>(g);
     return hv_check_launch();
+}
+
+template <typename DT, bool CONV>
+int launch(GemmArgs& g, hipStream_t stream) {
+    // narrow outputs (N <= 128: the VAE's 128-channel and output convs, small projections) take the 256x128 tile so that at
+    // most half a tile of MFMA work is padding
+    return g.N <= 128 ? launch_bn<DT, CONV, 128>(g, stream) : launch_bn<DT, CONV, 256>(g, stream);
 }
 
 int fill_common(GemmArgs& g, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, int M, int N, int K,

@@ -8,7 +8,7 @@ with open(sys.argv[1]) as f:
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         if "at::native" in r["Kernel_Name"] or name.startswith("void at::"):
             name = "torch (setup: synthetic weight/input generation, copies)"
-        key = (name, int(r["Grid_Size_X"]) if "attn_fwd" in name or "gemm_bf16" in name else 0)
+        key = (name, int(r["Grid_Size_X"]) if ("attn_fwd" in name or "gemm" in name) else 0)
         rows[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 tot = sum(sum(v) for v in rows.values())
 lines = ["| kernel | grid.x (threads) | launches | total ms | % | mean ms | min ms | max ms |", "|---|---|---|---|---|---|---|---|"]
