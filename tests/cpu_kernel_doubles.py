@@ -1,0 +1,146 @@
+"""TEST INFRASTRUCTURE: CPU stand-ins for the C-ABI kernels (hunyuanvideo_efficiency_amd.ops.*), built on the oracle's
+arithmetic, so that the HOST logic of the product (module wiring, workspaces, strided views, sequence-parallel sharding)
+can run under gloo on CPU with world_size > 1.  Never imported by the product; installed by tests via `install()`."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import dit_ref as R
+
+E = R.Prec(True)
+BF16 = torch.bfloat16
+
+
+def _bf(x):
+    return x.to(BF16)
+
+
+def ln_modulate(x, shift=None, scale=None, out=None, eps=1e-6, affine=False):
+    xf = x.float()
+    y = F.layer_norm(xf, (x.shape[-1],), None, None, eps)
+    if affine:
+        y = y * scale.float() + shift.float()
+    else:
+        if scale is not None:
+            y = y * E.r(1.0 + scale.float())
+        if shift is not None:
+            y = y + shift.float()
+    r = _bf(y)
+    if out is None:
+        return r
+    out.copy_(r)
+    return out
+
+
+def qknorm_rope_(qkv, q_weight, k_weight, cos, sin, n_rope, n_heads, k_offset, eps=1e-6):
+    n = qkv.shape[0]
+    d = n_heads * 128
+    for off, w in ((0, q_weight), (k_offset, k_weight)):
+        x = qkv[:, off:off + d].float().reshape(1, n, n_heads, 128)
+        y = R.rms_norm(x, w.float(), E, eps)
+        if n_rope:
+            y = torch.cat([R.apply_rope(y[:, :n_rope], cos[:n_rope].float(), sin[:n_rope].float(), E), y[:, n_rope:]], 1)
+        qkv[:, off:off + d] = _bf(y.reshape(n, d))
+    return qkv
+
+
+def _act(y, act):
+    if act == 1:
+        return R.gelu_tanh(y, E)
+    if act == 2:
+        return E.r(F.silu(y))
+    return y
+
+
+def gemm(a, w, bias=None, out=None, act=0, n_split=0, out1=None, act1=0, gate=None, res=None):
+    y = E.r(a.float() @ w.float().T + (0 if bias is None else bias.float()))
+    n = w.shape[0]
+    n0 = n_split if 0 < n_split < n else n
+    if gate is not None:
+        r = _bf(res.float() + E.r(_act(y, act) * gate.float()))
+    else:
+        r = _bf(_act(y[:, :n0], act))
+    if out is None:
+        out = torch.empty(a.shape[0], n0, dtype=BF16)
+    out[:, :n0] = r[:, :n0]
+    if n0 < n:
+        out1[:, :n - n0] = _bf(_act(y[:, n0:], act1))
+    return out
+
+
+def linear_smallm(x, w, bias=None, silu_in=False, silu_out=False, out=None, addend=None):
+    xf = x.float()
+    if silu_in:
+        xf = E.r(F.silu(xf))
+    y = E.r(xf @ w.float().T + (0 if bias is None else bias.float()))
+    if silu_out:
+        y = E.r(F.silu(y))
+    if addend is not None:
+        y = E.r(y + addend.float())
+    r = _bf(y)
+    if out is None:
+        return r
+    out.copy_(r)
+    return out
+
+
+def attn_fwd(q, k, v, out, n_heads, scale=None):
+    o = R.sdpa(q.float().reshape(1, q.shape[0], n_heads, 128), k.float().reshape(1, k.shape[0], n_heads, 128),
+               v.float().reshape(1, v.shape[0], n_heads, 128), E)
+    out.copy_(_bf(o.reshape(q.shape[0], n_heads * 128)))
+    return out
+
+
+def patchify(x_f32, out=None):
+    c, t, h, w = x_f32.shape
+    r = _bf(x_f32.reshape(c, t, h // 2, 2, w // 2, 2).permute(1, 2, 4, 0, 3, 5).reshape(t * (h // 2) * (w // 2), c * 4))
+    if out is None:
+        return r
+    out.copy_(r)
+    return out
+
+
+def unpatchify(y, c, t, h, w, out=None):
+    return _bf(R.unpatchify(y.float()[None], t, h // 2, w // 2, c, [1, 2, 2])[0])
+
+
+def euler_step_(sample_f32, model_out_bf16, dt):
+    sample_f32.add_(model_out_bf16.float() * dt)
+    return sample_f32
+
+
+def masked_mean(x, mask_i32=None):
+    if mask_i32 is None:
+        return _bf(x.float().mean(0))
+    m = mask_i32.float()[:, None]
+    return _bf((x.float() * m).sum(0) / m.sum())
+
+
+def broadcast_row_(src, dst):
+    dst.copy_(src[None].expand_as(dst))
+    return dst
+
+
+def timestep_embedding(t_f32, dim=256, max_period=10000.0):
+    return _bf(R.timestep_embedding(t_f32.reshape(-1), dim, max_period))
+
+
+def copy3d(src, dst, n_batch, rows, cols, src_bs, src_ld, dst_bs, dst_ld):
+    s = torch.as_strided(src, (n_batch, rows, cols), (src_bs, src_ld, 1), src.storage_offset())
+    d = torch.as_strided(dst, (n_batch, rows, cols), (dst_bs, dst_ld, 1), dst.storage_offset())
+    d.copy_(s)
+    return dst
+
+
+NAMES = ["ln_modulate", "qknorm_rope_", "gemm", "linear_smallm", "attn_fwd", "patchify", "unpatchify", "euler_step_",
+         "masked_mean", "broadcast_row_", "timestep_embedding", "copy3d"]
+
+
+def install():
+    """Replace the kernel wrappers of hunyuanvideo_efficiency_amd.ops with the CPU doubles (test processes only)."""
+    from hunyuanvideo_efficiency_amd import ops
+    g = globals()
+    for n in NAMES:
+        setattr(ops, n, g[n])
+    return ops
