@@ -23,7 +23,8 @@ SIGNATURES = {
     "hv_gemm_bf16": [_p, _l, _p, _l, _p, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p, _p, _l, _p],
     "hv_linear_smallm_bf16": [_p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _i, _p],
     "hv_timestep_embedding_bf16": [_p, _p, _i, _i, _f, _p],
-    "hv_attn_fwd_bf16": [_p, _p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _f, _p],
+    "hv_attn_fwd_bf16": [_p, _p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _f, _p, _l, _p],
+    "hv_attn_workspace_bytes": [_i, _i, _i],
     "hv_patchify_f32_bf16": [_p, _p, _i, _i, _i, _i, _p],
     "hv_unpatchify_bf16": [_p, _p, _i, _i, _i, _i, _l, _p],
     "hv_euler_step_f32": [_p, _p, _f, _l, _p],
@@ -67,7 +68,7 @@ def load():
         except AttributeError as e:
             raise HVKernelError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name == "hv_attn_workspace_bytes" else C.c_int
     v = lib.hv_abi_version()
     if v != ABI_VERSION:
         raise HVKernelError(f"libhv_kernels ABI {v} != expected {ABI_VERSION}: rebuild the extension")

@@ -38,6 +38,11 @@ struct AttnArgs {
     int64_t sq, sk, sv, so;   // token strides (elements); head h lives at column h*128
     int n_q, n_kv, n_heads, n_qtiles;
     float scale_log2e;
+    // KV split (load balance when the grid is only a few rounds of workgroups): blockIdx.y = split s handles keys
+    // [s*split_keys, min(n_kv, (s+1)*split_keys)); partial O (unnormalised, fp32) and (m, l) go to the workspace
+    int n_splits, split_keys;
+    float* part_o;      // [n_splits][n_q][n_heads][128]
+    float* part_ml;     // [n_splits][n_q][n_heads][2]
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -70,6 +75,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v2(AttnArgs a) {
     const int lr = lane & 31, lh = lane >> 5;
     const int head = blockIdx.x / a.n_qtiles;
     const int qt = blockIdx.x % a.n_qtiles;
+    if (a.n_splits > 1) {   // this workgroup's key range
+        const int kv0 = blockIdx.y * a.split_keys;
+        a.k += (int64_t)kv0 * a.sk;
+        a.v += (int64_t)kv0 * a.sv;
+        a.n_kv = min(a.n_kv - kv0, a.split_keys);
+    }
     const int q0 = qt * QTILE + wave * QROWS_WAVE;
     constexpr int KOFF = 0, VOFF = 2 * KV_TILE_BYTES;
 
@@ -250,6 +261,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v2(AttnArgs a) {
     }
 
     const float l_tot = half_swap_sum(l_run);
+    if (a.n_splits > 1) {   // partial result: O^T unnormalised (fp32) + (m, l); merged by attn_combine_kernel
+        const int qrow_p = q0 + lr;
+        if (qrow_p < a.n_q) {
+            const int64_t rowi = ((int64_t)blockIdx.y * a.n_q + qrow_p) * a.n_heads + head;
+            float* po = a.part_o + rowi * D + 4 * lh;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(po + db * 32 + g * 8) =
+                        make_float4(oT[db][4 * g], oT[db][4 * g + 1], oT[db][4 * g + 2], oT[db][4 * g + 3]);
+            if (lh == 0) {
+                a.part_ml[rowi * 2] = m_run;
+                a.part_ml[rowi * 2 + 1] = l_tot;
+            }
+        }
+        return;
+    }
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + lr;
     if (qrow < a.n_q) {
@@ -266,11 +295,46 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v2(AttnArgs a) {
     }
 }
 
+
+// merge the KV-split partials: O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m),  m = max_s m_s  (log2 domain)
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                            bf16_t* __restrict__ o, int64_t so, int n_q, int n_heads, int n_splits) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (row, head, 4 dims)
+    const int64_t total = (int64_t)n_q * n_heads * 32;
+    if (idx >= total) return;
+    const int d4 = (int)(idx & 31);
+    const int64_t rh = idx >> 5;            // row * n_heads + head
+    const int head = (int)(rh % n_heads);
+    const int64_t row = rh / n_heads;
+    float m = -INFINITY;
+    for (int s = 0; s < n_splits; ++s) m = fmaxf(m, part_ml[(((int64_t)s * n_q + row) * n_heads + head) * 2]);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float l = 0.f;
+    for (int s = 0; s < n_splits; ++s) {
+        const int64_t ri = ((int64_t)s * n_q + row) * n_heads + head;
+        const float w = __builtin_amdgcn_exp2f(part_ml[ri * 2] - m);
+        const float4 v = *reinterpret_cast<const float4*>(part_o + ri * D + d4 * 4);
+        acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+        l += part_ml[ri * 2 + 1] * w;
+    }
+    const float inv = 1.0f / l;
+    u32x2 w2;
+    w2[0] = pack_bf2(acc.x * inv, acc.y * inv);
+    w2[1] = pack_bf2(acc.z * inv, acc.w * inv);
+    *reinterpret_cast<u32x2*>(o + row * so + head * D + d4 * 4) = w2;
+}
+
 }  // namespace
+
+extern "C" int64_t hv_attn_workspace_bytes(int n_q, int n_kv, int n_heads) {
+    // enough for a 2-way KV split (used only when the grid is a few workgroup rounds deep; see hv_attn_fwd_bf16)
+    (void)n_kv;
+    return (int64_t)2 * n_q * n_heads * (128 + 2) * (int64_t)sizeof(float);
+}
 
 extern "C" int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t stride_q, int64_t stride_k,
                                 int64_t stride_v, int64_t stride_o, int n_q, int n_kv, int n_heads, int head_dim,
-                                float scale, hipStream_t stream) {
+                                float scale, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
     if (!q || !k || !v || !o || head_dim != D || n_heads <= 0 || n_q < 0 || n_kv < 0 || (stride_q & 7) || (stride_k & 7) ||
         (stride_v & 7) || (stride_o & 3))
         return HV_ERR_ARG;
@@ -288,6 +352,26 @@ extern "C" int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
             return HV_ERR_LAUNCH;
         attr_set = true;
     }
-    attn_fwd_kernel_v2<<<dim3((unsigned)(a.n_qtiles * n_heads)), dim3(512), ATT_LDS, stream>>>(a);
+    // Load balance: workgroups are equal-cost items on 256 CUs; with only a few rounds (e.g. 3 heads per rank under Ulysses-8:
+    // 1395 items = 5.45 rounds -> 6) a partially filled last round costs a whole item.  Splitting the key range in two makes
+    // the items half as long (2790 items = 10.9 -> 11 half-rounds = 5.5): taken when it shortens the makespan by > 3 %.
+    a.n_splits = 1; a.split_keys = n_kv; a.part_o = nullptr; a.part_ml = nullptr;
+    {
+        const int64_t nwg = (int64_t)a.n_qtiles * n_heads;
+        const int ntile = (n_kv + KVT - 1) / KVT;
+        const double r1 = (double)((nwg + 255) / 256), r2 = 0.5 * (double)((2 * nwg + 255) / 256);
+        if (workspace && ntile >= 64 && r2 < 0.97 * r1 && workspace_bytes >= hv_attn_workspace_bytes(n_q, n_kv, n_heads)) {
+            a.n_splits = 2;
+            a.split_keys = ((ntile + 1) / 2) * KVT;
+            a.part_o = (float*)workspace;
+            a.part_ml = a.part_o + (int64_t)2 * n_q * n_heads * D;
+        }
+    }
+    attn_fwd_kernel_v2<<<dim3((unsigned)(a.n_qtiles * n_heads), (unsigned)a.n_splits), dim3(512), ATT_LDS, stream>>>(a);
+    if (a.n_splits > 1) {
+        const int64_t total = (int64_t)n_q * n_heads * 32;
+        attn_combine_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(a.part_o, a.part_ml, a.o, a.so, n_q, n_heads,
+                                                                                           a.n_splits);
+    }
     return hv_check_launch();
 }

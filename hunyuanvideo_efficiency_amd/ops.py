@@ -129,7 +129,24 @@ def linear_smallm(x, w, bias=None, silu_in: bool = False, silu_out: bool = False
     return out
 
 
-def attn_fwd(q, k, v, out, n_heads: int, scale: Optional[float] = None):
+_attn_ws = {}
+
+
+def _attn_workspace(n_q, n_kv, n_heads, device):
+    """Scratch for the kernel's optional KV split (load balance of shallow grids); only allocated for shallow grids."""
+    n_wg = ((n_q + 255) // 256) * n_heads
+    if n_wg >= 16 * 256 or n_kv < 64 * 64:
+        return None
+    need = int(_lib.load().hv_attn_workspace_bytes(n_q, n_kv, n_heads))
+    key = str(device)
+    ws = _attn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _attn_ws[key] = ws
+    return ws
+
+
+def attn_fwd(q, k, v, out, n_heads: int, scale: Optional[float] = None, kv_split_workspace: bool = True):
     """q:[n_q, >=H*128] k,v:[n_kv, ...] out:[n_q, ...] 2-D views (token rows, head h at column h*128)."""
     for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
         _chk(t, BF16, nm)
@@ -142,8 +159,10 @@ def attn_fwd(q, k, v, out, n_heads: int, scale: Optional[float] = None):
     if prof is not None:   # bench.py: HIP events on the launch stream around the dominant kernel
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    ws = _attn_workspace(n_q, n_kv, n_heads, q.device) if kv_split_workspace else None
     _lib.check(_lib.load().hv_attn_fwd_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), q.stride(0), k.stride(0), v.stride(0),
-                                            out.stride(0), n_q, n_kv, n_heads, 128, scale, _stream()), "hv_attn_fwd_bf16")
+                                            out.stride(0), n_q, n_kv, n_heads, 128, scale, _ptr(ws),
+                                            0 if ws is None else ws.numel(), _stream()), "hv_attn_fwd_bf16")
     if prof is not None:
         e1.record()
         prof.append((e0, e1, n_q, n_kv, n_heads))

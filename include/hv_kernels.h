@@ -69,10 +69,17 @@ int hv_timestep_embedding_bf16(const float* t, void* out, int n_t, int dim, floa
 /* K6/K6': softmax(scale * q k^T) v, bf16, head_dim 128, non-causal, over ONE contiguous key segment
  * (flash_attn_varlen_func / _flash_attn_forward of modules/attenion.py:107-120,181-207: the caller
  * issues one call per cu_seqlens segment).  q/k/v/o: token-major, head h at column h*128 of each row;
- * strides in elements (so q,k,v may point into one fused QKV buffer and o into a wider concat buffer). */
+ * strides in elements (so q,k,v may point into one fused QKV buffer and o into a wider concat buffer).
+ * workspace (nullable): caller-owned scratch of hv_attn_workspace_bytes(n_q, n_kv, n_heads) bytes.  When given and the
+ * launch would be only a few workgroup rounds deep (e.g. 3 heads per rank under Ulysses-8), the key range is split in two
+ * halves processed by separate workgroups and merged (log-sum-exp) by a second tiny kernel: shorter makespan, same result
+ * up to fp32 rounding.  Without a workspace the single-pass kernel always runs. */
 int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t stride_q, int64_t stride_k,
                      int64_t stride_v, int64_t stride_o, int n_q, int n_kv, int n_heads, int head_dim,
-                     float scale, hipStream_t stream);
+                     float scale, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* bytes of scratch hv_attn_fwd_bf16 can use for the KV split (returned as int64). */
+int64_t hv_attn_workspace_bytes(int n_q, int n_kv, int n_heads);
 
 /* K10 gather: fp32 latent [C,T,H,W] -> bf16 patch rows [T*(H/2)*(W/2), C*4] (embed_layers.py:40-59). */
 int hv_patchify_f32_bf16(const float* x, void* A, int C, int T, int H, int W, hipStream_t stream);

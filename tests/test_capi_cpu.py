@@ -12,7 +12,7 @@ def _header_decls():
     src = open(os.path.join(ROOT, "include", "hv_kernels.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\bint\s+(hv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|int64_t)\s+(hv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         decls[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     return decls
