@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="720p129f", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sp", action="store_true", help="N=1 only: run the sequence-parallel code path on a 1-rank RCCL group "
+                    "(pack/unpack + self all-to-all + chunked QKV GEMMs) to price its overhead")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-by-`value`) VAE tiled decode of the same video")
     a = ap.parse_args()
 
@@ -93,9 +95,10 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or a.force_sp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from hunyuanvideo_efficiency_amd import _lib, ops, synthetic as syn
     from hunyuanvideo_efficiency_amd.selftest import build_model
@@ -108,7 +111,7 @@ def main():
     T, H, W = WORKLOADS[a.workload]
     s_img, s_txt = T * (H // 2) * (W // 2), 256
     model = build_model(cfg, dev, seed=0)
-    if world > 1:
+    if world > 1 or a.force_sp:
         from hunyuanvideo_efficiency_amd.inference import parallelize_transformer_module
         parallelize_transformer_module(model, dist.group.WORLD)
     x, ts, tm, ts2 = syn.synth_dit_inputs(cfg, (T, H, W), s_txt, 11, seed=42, device=dev)
@@ -193,7 +196,7 @@ def main():
             "dtype": "bf16", "data": "synthetic (hash-generated latents/text embeddings, random-init weights)",
             "config": {"workload": f"{a.workload}: latent 16x{T}x{H}x{W}, S_img={s_img}, S_txt={s_txt} (11 valid), "
                                    f"d={cfg.hidden_size}, heads={cfg.heads_num}, {cfg.mm_double_blocks_depth}+{cfg.mm_single_blocks_depth} blocks",
-                       "parallelism": "single GPU" if world == 1 else f"ulysses{world} (token-axis shard, RCCL all-to-all)"},
+                       "parallelism": ("single GPU" + (" (SP code path forced on a 1-rank group)" if a.force_sp else "")) if world == 1 else f"ulysses{world} (token-axis shard, RCCL all-to-all)"},
             "sec_per_video_50steps_denoise_only": 50 * ms_per_step / 1e3,
             "vae_tiled_decode_s": vae_s,
             "sec_per_video_50steps_plus_vae_decode": (50 * ms_per_step / 1e3 + vae_s) if vae_s is not None else None,
@@ -207,7 +210,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(f_step)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or a.force_sp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -94,6 +94,49 @@ class UlyssesLongContextAttention:
             dist.all_gather_into_tensor(recv_t, full["of"][s_img:].contiguous(), group=self.group)
             self.k.copy3d(recv_t, out[s_loc:], P, n_j, w, n_j * w, w, w, ld_out)
 
+    # ------------------------------------------------------------------ overlapped form (exchange under the QKV GEMMs)
+    # The block computes q, k, v with three column-chunk GEMMs and hands each chunk over as soon as it is ready:
+    #   GEMM_q -> norm/rope -> send("q") | GEMM_k -> norm -> send("k") | GEMM_v -> send("v") | [single block: GEMM_mlp+GELU]
+    # Each send packs on the compute stream and starts an ASYNC all-to-all (RCCL runs it on its own stream), so the
+    # exchange of chunk i travels over xGMI while the MFMA GEMM of chunk i+1 runs; attend() waits for the three handles.
+    def begin(self, s_loc: int, n_j: int, heads: int, device):
+        P, rank = self._world()
+        if heads % P != 0:
+            raise ValueError(f"Ulysses degree {P} must divide the head count {heads} (hybrid ring attention is not built)")
+        w = (heads // P) * 128
+        self._geo = (P, rank, s_loc, n_j, heads, w)
+        n_tot = P * s_loc + n_j
+        for n in ("qf", "kf", "vf", "of"):
+            self._buf(n, (n_tot, w), device)
+        self._works = []
+
+    def send(self, which: str, src: torch.Tensor, ld_src: int, joint: Optional[torch.Tensor], ld_j: int):
+        """src: view whose data_ptr is (local image row 0, head 0) of the q / k / v chunk; joint: same for the valid text rows."""
+        P, rank, s_loc, n_j, heads, w = self._geo
+        name = {"q": "qf", "k": "kf", "v": "vf"}[which]
+        full = self._bufs[name]
+        send = self._buf("send_" + which, (P * s_loc, w), src.device)      # one send buffer per tensor: exchanges overlap
+        self.k.copy3d(src, send, P, s_loc, w, w, ld_src, s_loc * w, w)
+        self._works.append(dist.all_to_all_single(full[:P * s_loc], send, group=self.group, async_op=True))
+        if n_j:
+            self.k.copy3d(joint[:, rank * w:], full[P * s_loc:], 1, n_j, w, 0, ld_j, 0, w)
+
+    def attend(self, out: torch.Tensor, ld_out: int):
+        P, rank, s_loc, n_j, heads, w = self._geo
+        for wk in self._works:
+            wk.wait()                       # the compute stream waits for the exchanges (no host sync)
+        self._works = []
+        b = self._bufs
+        s_img = P * s_loc
+        self.k.attn_fwd(b["qf"], b["kf"], b["vf"], b["of"], heads // P)
+        recv = self._buf("recv", (s_img, w), out.device)
+        dist.all_to_all_single(recv, b["of"][:s_img], group=self.group)
+        self.k.copy3d(recv, out, P, s_loc, w, s_loc * w, w, w, ld_out)
+        if n_j:
+            recv_t = self._buf("recv_t", (P * n_j, w), out.device)
+            dist.all_gather_into_tensor(recv_t, b["of"][s_img:].contiguous(), group=self.group)
+            self.k.copy3d(recv_t, out[s_loc:], P, n_j, w, n_j * w, w, w, ld_out)
+
     # ------------------------------------------------------------------ reference hook signature
     def __call__(self, attn, query, key, value, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
                  alibi_slopes=None, deterministic=False, return_attn_probs=False, joint_tensor_query=None,

@@ -99,6 +99,12 @@ def segment_attention_(hybrid_seq_parallel_attn, qkv: torch.Tensor, cat: torch.T
         ops.attn_fwd(q[cu1:], k[cu1:], v[cu1:], o[cu1:], heads)
 
 
+def pad_segment_attention_(qkv: torch.Tensor, cat: torch.Tensor, cu1: int, heads: int, d: int):
+    """attn2 of parallel_attention (attenion.py:181-207): the padding-text rows [cu1, S) attend among themselves, locally."""
+    if qkv.shape[0] > cu1:
+        ops.attn_fwd(qkv[cu1:, :d], qkv[cu1:, d:2 * d], qkv[cu1:, 2 * d:], cat[cu1:, :d], heads)
+
+
 def parallel_attention(hybrid_seq_parallel_attn, q, k, v, img_q_len, img_kv_len, cu_seqlens_q, cu_seqlens_kv):
     """Reference signature (attenion.py:159-212): attn1 = SP attention of [img | valid text] with the text as
     the replicated joint tensor ("rear"), attn2 = plain attention over the padding text; concatenated."""

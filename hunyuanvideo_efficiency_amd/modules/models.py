@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .attenion import get_cu_seqlens, n_valid_text, segment_attention_
+from .attenion import get_cu_seqlens, n_valid_text, segment_attention_, pad_segment_attention_
 from .token_refiner import SingleTokenRefiner
 from .layers import ParamLinear, ParamNormWeight, ModulateDiT, MLP, MLPEmbedder, TimestepEmbedder, PatchEmbed, FinalLayer
 
@@ -42,6 +42,22 @@ class _Workspace:
         self.cat = torch.empty(s, d + mlp, dtype=BF16, device=device)
         self.patches = None
         self.final = None
+
+
+def _sp_chunked_qkv(sp, ws: _Workspace, w, b, q_norm_w, k_norm_w, cos, sin, s_img: int, cu1: int, n_rope: int, H: int, d: int):
+    """Sequence-parallel form of "QKV GEMM -> RMSNorm/RoPE -> all-to-all" for the local image rows [0, s_img): q, k and v are
+    produced by three column-chunk MFMA GEMMs (rows [c*d, (c+1)*d) of the fused weight) and each chunk is handed to the
+    Ulysses object as soon as it is normalised, so its RCCL all-to-all overlaps the next chunk's GEMM.  The text rows
+    [s_img, cu1) of ws.qkv (joint tensors, replicated on every rank) must already be final."""
+    ld = ws.qkv.stride(0)
+    sp.begin(s_img, cu1 - s_img, H, ws.qkv.device)
+    for c, which, norm_w in ((0, "q", q_norm_w), (1, "k", k_norm_w), (2, "v", None)):
+        chunk = ws.qkv[:s_img, c * d:(c + 1) * d]
+        ops.gemm(ws.xmod[:s_img], w[c * d:(c + 1) * d], None if b is None else b[c * d:(c + 1) * d], out=chunk)
+        if norm_w is not None:
+            # the kernel normalises 2 x (H/2) head vectors: with both halves given the same gain that is this chunk's H heads
+            ops.qknorm_rope_(chunk, norm_w, norm_w, cos, sin, n_rope, H // 2, (H // 2) * 128)
+        sp.send(which, chunk, ld, ws.qkv[s_img:cu1, c * d:(c + 1) * d], ld)
 
 
 class MMDoubleStreamBlock(nn.Module):
@@ -77,7 +93,10 @@ class MMDoubleStreamBlock(nn.Module):
             cos: Optional[torch.Tensor], sin: Optional[torch.Tensor]):
         d = ws.x.shape[1]
         H = self.heads_num
-        streams = (("img", 0, s_img, s_img if cos is not None else 0), ("txt", s_img, s_img + s_txt, 0))
+        # txt first: under sequence parallelism its (replicated) q/k/v rows are the joint tensors of the exchange
+        streams = (("txt", s_img, s_img + s_txt, 0), ("img", 0, s_img, s_img if cos is not None else 0))
+        sp = self.hybrid_seq_parallel_attn
+        overlap = sp is not None and hasattr(sp, "send") and H % 2 == 0
         mods = {}
         for s, lo, hi, n_rope in streams:
             mod = getattr(self, f"{s}_mod")
@@ -86,10 +105,19 @@ class MMDoubleStreamBlock(nn.Module):
             sh1, sc1 = mods[s][0], mods[s][1]
             ops.ln_modulate(ws.x[lo:hi], sh1, sc1, out=ws.xmod[lo:hi])
             qkv_l = getattr(self, f"{s}_attn_qkv")
-            ops.gemm(ws.xmod[lo:hi], qkv_l.w(), qkv_l.bias, out=ws.qkv[lo:hi])
-            ops.qknorm_rope_(ws.qkv[lo:hi], getattr(self, f"{s}_attn_q_norm").weight,
-                             getattr(self, f"{s}_attn_k_norm").weight, cos, sin, n_rope, H, d)
-        segment_attention_(self.hybrid_seq_parallel_attn, ws.qkv, ws.cat, s_img, cu1, H, d)
+            qw, kw = getattr(self, f"{s}_attn_q_norm").weight, getattr(self, f"{s}_attn_k_norm").weight
+            if overlap and s == "img":
+                # q / k / v as three column-chunk GEMMs; each chunk's all-to-all travels while the next chunk's GEMM runs
+                _sp_chunked_qkv(sp, ws, qkv_l.w(), qkv_l.bias, qw, kw, cos, sin, s_img, cu1, n_rope, H, d)
+            else:
+                ops.gemm(ws.xmod[lo:hi], qkv_l.w(), qkv_l.bias, out=ws.qkv[lo:hi])
+                ops.qknorm_rope_(ws.qkv[lo:hi], qw, kw, cos, sin, n_rope, H, d)
+        if overlap:
+            sp.attend(ws.cat, ws.cat.stride(0))
+            pad_segment_attention_(ws.qkv, ws.cat, cu1, H, d)
+        else:
+            segment_attention_(sp, ws.qkv, ws.cat, s_img, cu1, H, d)
+        streams = (streams[1], streams[0])
         for s, lo, hi, _ in streams:
             _, _, g1, sh2, sc2, g2 = mods[s]
             proj, mlp = getattr(self, f"{s}_attn_proj"), getattr(self, f"{s}_mlp")
@@ -149,11 +177,26 @@ class MMSingleStreamBlock(nn.Module):
         m = ops.linear_smallm(vec, self.modulation.linear.w(), self.modulation.linear.bias, silu_in=True)
         shift, scale, gate = m[0, :d], m[0, d:2 * d], m[0, 2 * d:]
         ops.ln_modulate(ws.x, shift, scale, out=ws.xmod)
-        # linear1: cols [0,3d) -> qkv ; cols [3d, 3d+mlp) -> GELU-tanh -> cat[:, d:]   (models.py:339-341,392)
-        ops.gemm(ws.xmod, self.linear1.w(), self.linear1.bias, out=ws.qkv, n_split=3 * d, out1=ws.cat[:, d:],
-                 act1=ops.ACT_GELU_TANH)
-        ops.qknorm_rope_(ws.qkv, self.q_norm.weight, self.k_norm.weight, cos, sin, s_img if cos is not None else 0, H, d)
-        segment_attention_(self.hybrid_seq_parallel_attn, ws.qkv, ws.cat, s_img, cu1, H, d)
+        sp = self.hybrid_seq_parallel_attn
+        n_rope = s_img if cos is not None else 0
+        if sp is not None and hasattr(sp, "send") and H % 2 == 0:
+            # sequence parallel: q | k | v | mlp as four column-chunk GEMMs of linear1; the all-to-all of each attention chunk
+            # runs on RCCL's stream under the following chunk's MFMA GEMM (the 12288-wide mlp chunk covers the v exchange)
+            w1, b1 = self.linear1.w(), self.linear1.bias
+            s_tot = ws.x.shape[0]
+            # text rows of all three chunks first (they are the joint tensors every send needs)
+            ops.gemm(ws.xmod[s_img:], w1[:3 * d], b1[:3 * d], out=ws.qkv[s_img:])
+            ops.qknorm_rope_(ws.qkv[s_img:], self.q_norm.weight, self.k_norm.weight, None, None, 0, H, d)
+            _sp_chunked_qkv(sp, ws, w1, b1, self.q_norm.weight, self.k_norm.weight, cos, sin, s_img, cu1, n_rope, H, d)
+            ops.gemm(ws.xmod, w1[3 * d:], b1[3 * d:], out=ws.cat[:, d:], act=ops.ACT_GELU_TANH)
+            sp.attend(ws.cat, ws.cat.stride(0))
+            pad_segment_attention_(ws.qkv, ws.cat, cu1, H, d)
+        else:
+            # linear1: cols [0,3d) -> qkv ; cols [3d, 3d+mlp) -> GELU-tanh -> cat[:, d:]   (models.py:339-341,392)
+            ops.gemm(ws.xmod, self.linear1.w(), self.linear1.bias, out=ws.qkv, n_split=3 * d, out1=ws.cat[:, d:],
+                     act1=ops.ACT_GELU_TANH)
+            ops.qknorm_rope_(ws.qkv, self.q_norm.weight, self.k_norm.weight, cos, sin, n_rope, H, d)
+            segment_attention_(sp, ws.qkv, ws.cat, s_img, cu1, H, d)
         ops.gemm(ws.cat, self.linear2.w(), self.linear2.bias, out=ws.x, gate=gate, res=ws.x)
 
     def forward(self, x, vec, txt_len, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
