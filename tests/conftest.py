@@ -12,6 +12,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-process tests start their ranks from a fork server that is launched HERE, before any test has touched the GPU:
+    # a process that has initialised HIP must never exec (the GPU boxes refuse it), and fork-without-exec of such a process
+    # would hand the children a stale HIP state.
+    import multiprocessing
+    import multiprocessing.forkserver as forkserver
+    try:
+        multiprocessing.set_forkserver_preload(["torch"])
+        forkserver.ensure_running()
+    except Exception:  # noqa: BLE001 - platforms without forkserver: the multi-process tests fall back to spawn
+        pass
 
 
 @pytest.fixture(scope="session")
