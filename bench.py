@@ -147,7 +147,8 @@ def main():
     prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
     # end-to-end leg (reported beside `value`, never part of it): VAE tiled decode of this video's latents on rank 0's GPU
     vae_s = None
-    if not tiny and not a.no_vae and rank == 0:
+    if not tiny and not a.no_vae:
+        # N > 1: the 84 tiles are shared out over the ranks (AutoencoderKLCausal3D.enable_tile_parallel), all ranks take part
         from hunyuanvideo_efficiency_amd.vae import AutoencoderKLCausal3D
         vae = AutoencoderKLCausal3D(device=dev)
         with torch.no_grad():
@@ -156,10 +157,12 @@ def main():
         vae.enable_tiling()
         z = syn.hashed_uniform((1, 16, T, H, W), "vae.z", 0, dev) * 1.7
         vae.decode(z[:, :, :5, :32, :32], return_dict=False)           # warm-up (weight re-layout, kernel load)
-        torch.cuda.synchronize()
+        if world > 1:
+            vae.enable_tile_parallel()
+        barrier()
         t0 = time.perf_counter()
         img = vae.decode(z, return_dict=False)[0]
-        torch.cuda.synchronize()
+        barrier()
         vae_s = time.perf_counter() - t0
         assert bool(torch.isfinite(img).all())
         del vae, img, z

@@ -73,6 +73,9 @@ def parallelize_transformer_module(transformer, group=None, kernels=None):
 def parallelize_transformer(pipe):
     """Reference entry point (inference.py:40): patches pipe.transformer in place."""
     parallelize_transformer_module(pipe.transformer)
+    vae = getattr(pipe, "vae", None)
+    if vae is not None and hasattr(vae, "enable_tile_parallel"):
+        vae.enable_tile_parallel()      # beyond the reference (which decodes every tile on every rank): SURVEY.md 8e
 
 
 def get_rotary_pos_embed(transformer, video_length: int, height: int, width: int, vae: str = "884-16c-hy",

@@ -246,10 +246,91 @@ class AutoencoderKLCausal3D(nn.Module):
         return buf.as_strided((c, T, H, W), (1, H * W * buf.stride(0), W * buf.stride(0), buf.stride(0)), buf.storage_offset())
 
     def _plain_decode(self, z4):
-        buf, T, H, W = self._decode_tile(z4)
+        buf, T, H, W = self._take_tile(z4)
         out = torch.empty(3, T, H, W, dtype=F16, device=buf.device)
         V.copy4d_(self._cl_view(buf, T, H, W), out)
         return out
+
+    # ------------------------------------------------------------------ tile parallelism (new vs the reference,
+    # which decodes every tile on every rank).  Tiles are independent until the blend: each rank decodes its share, the decoded
+    # tiles are all-gathered (one RCCL all-gather per round of P tiles, in flight while the next round decodes), and every rank
+    # runs the reference's blend loops over the complete set, so decode() still returns the whole video on every rank.
+    def enable_tile_parallel(self, group=None, enable: bool = True):
+        self._tp_enabled = enable
+        self._tp_group = group
+
+    def _spatial_views(self, z4):
+        ov = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
+        for i in range(0, z4.shape[-2], ov):
+            for j in range(0, z4.shape[-1], ov):
+                yield z4[:, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size]
+
+    def _needs_spatial(self, z4):
+        return self.use_spatial_tiling and (z4.shape[-1] > self.tile_latent_min_size or z4.shape[-2] > self.tile_latent_min_size)
+
+    def _tile_views(self, z4):
+        """Latent views of every tile, in exactly the order the decode loops below consume them."""
+        if self.use_temporal_tiling and z4.shape[1] > self.tile_latent_min_tsize:
+            ov = int(self.tile_latent_min_tsize * (1 - self.tile_overlap_factor))
+            for i in range(0, z4.shape[1], ov):
+                tile = z4[:, i:i + self.tile_latent_min_tsize + 1]
+                if self._needs_spatial(tile):
+                    yield from self._spatial_views(tile)
+                else:
+                    yield tile
+        elif self._needs_spatial(z4):
+            yield from self._spatial_views(z4)
+        else:
+            yield z4
+
+    @staticmethod
+    def _assign_tiles(costs: List[int], world: int) -> List[List[int]]:
+        """Longest-processing-time-first: tiles in descending cost, each to the least-loaded rank (ties -> lowest rank).
+        Deterministic, so every rank derives the same plan without communicating."""
+        load = [0] * world
+        plan: List[List[int]] = [[] for _ in range(world)]
+        for k in sorted(range(len(costs)), key=lambda k: (-costs[k], k)):
+            r = min(range(world), key=lambda r: (load[r], r))
+            plan[r].append(k)
+            load[r] += costs[k]
+        return plan
+
+    def _decode_tiles_sharded(self, z4, group):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        views = list(self._tile_views(z4))
+        tc = self.time_compression_ratio
+        dims = [((v.shape[1] - 1) * tc + 1, v.shape[2] * 8, v.shape[3] * 8) for v in views]     # decoded T', H', W'
+        plan = self._assign_tiles([v.shape[1] * v.shape[2] * v.shape[3] for v in views], world)
+        rounds = max(len(p) for p in plan)
+        max_rows = max(t * h * w for t, h, w in dims)
+        gathered = torch.empty(rounds, world, max_rows, 8, dtype=F16, device=z4.device)
+        mine = torch.zeros(rounds, max_rows, 8, dtype=F16, device=z4.device)
+        works = []
+        for r in range(rounds):
+            if r < len(plan[rank]):
+                k = plan[rank][r]
+                buf, T, H, W = self._decode_tile(views[k])
+                assert (T, H, W) == dims[k] and buf.shape[1] == 8
+                mine[r, :buf.shape[0]].copy_(buf)
+            works.append(dist.all_gather_into_tensor(gathered[r].view(world * max_rows, 8), mine[r], group=group, async_op=True))
+        for w in works:
+            w.wait()
+        out = [None] * len(views)
+        for p in range(world):
+            for r, k in enumerate(plan[p]):
+                t, h, w = dims[k]
+                out[k] = (gathered[r, p, :t * h * w], t, h, w)
+        return out
+
+    def _take_tile(self, z_view):
+        """The decode loops' tile source: decode here, or (tile-parallel) the next pre-decoded tile."""
+        q = getattr(self, "_tile_queue", None)
+        if q is None:
+            return self._decode_tile(z_view)
+        buf, T, H, W = q.pop(0)
+        assert (T, H, W) == ((z_view.shape[1] - 1) * self.time_compression_ratio + 1, z_view.shape[2] * 8, z_view.shape[3] * 8)
+        return buf, T, H, W
 
     def _spatial_tiled_decode(self, z4):
         """autoencoder_kl_causal_3d.py:422-469 on a [C,T,H,W] view; returns planar fp16 [3,T',H',W']."""
@@ -260,7 +341,7 @@ class AutoencoderKLCausal3D(nn.Module):
         for i in range(0, z4.shape[-2], ov):
             row = []
             for j in range(0, z4.shape[-1], ov):
-                buf, T, H, W = self._decode_tile(z4[:, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size])
+                buf, T, H, W = self._take_tile(z4[:, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size])
                 row.append(self._cl_view(buf, T, H, W))
             rows.append(row)
         heights = [min(r[0].shape[2], lim) for r in rows]
@@ -317,6 +398,17 @@ class AutoencoderKLCausal3D(nn.Module):
         if z.shape[0] != 1:
             raise NotImplementedError("batch 1 (use_slicing splits larger batches)")
         z4 = z[0].to(torch.float32)
+        self._tile_queue = None
+        if getattr(self, "_tp_enabled", False):
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self._tp_group) > 1:
+                self._tile_queue = self._decode_tiles_sharded(z4, self._tp_group)
+        try:
+            return self._decode_assembled(z4)
+        finally:
+            self._tile_queue = None
+
+    def _decode_assembled(self, z4):
         if self.use_temporal_tiling and z4.shape[1] > self.tile_latent_min_tsize:
             return self._temporal_tiled_decode(z4)[None]
         if self.use_spatial_tiling and (z4.shape[-1] > self.tile_latent_min_size or z4.shape[-2] > self.tile_latent_min_size):
