@@ -5,18 +5,31 @@ import torch
 
 from .autoencoder_kl_causal_3d import AutoencoderKLCausal3D  # noqa: F401
 
+# constructor arguments config.json may carry (autoencoder_kl_causal_3d.py:60-82 in the reference)
+_CONFIG_KEYS = ("in_channels", "out_channels", "down_block_types", "up_block_types", "block_out_channels", "layers_per_block",
+                "act_fn", "latent_channels", "norm_num_groups", "sample_size", "sample_tsize", "scaling_factor", "force_upcast",
+                "spatial_compression_ratio", "time_compression_ratio", "mid_block_add_attention")
+
 
 def load_vae(vae_type: str = "884-16c-hy", vae_precision: str = "fp16", sample_size=None, vae_path=None, logger=None,
              device=None, state_dict=None):
     """Builds the 884-16c-hy topology (block_out_channels (128,256,512,512), 16 latent channels).
-    `state_dict`: reference-format weights (keys decoder.*, post_quant_conv.*; encoder.* ignored).  Checkpoint FILES are
-    loaded by the caller with torch.load(weights_only=True); this function never unpickles."""
+    `vae_path`: directory with the reference's `config.json` + `pytorch_model.pt` (read by checkpoint.read_vae_checkpoint with
+    torch.load(weights_only=True); "state_dict" wrapper and "vae." prefix handled as vae/__init__.py:97-101).
+    `state_dict`: already-loaded reference-format weights (keys decoder.*, post_quant_conv.*; encoder.* ignored)."""
     if vae_type != "884-16c-hy":
         raise NotImplementedError(f"VAE type {vae_type}: only the shipped 884-16c-hy decoder topology has kernels")
     dtype = {"fp16": torch.float16}.get(vae_precision)
     if dtype is None:
         raise NotImplementedError("VAE kernels are fp16 (the reference default --vae-precision fp16)")
     kw = {}
+    if vae_path is not None and state_dict is None:
+        from ..checkpoint import read_vae_checkpoint
+        if logger is not None:
+            logger.info(f"Loading 3D VAE model ({vae_type}) from: {vae_path}")
+        state_dict, cfg = read_vae_checkpoint(vae_path)
+        if cfg:
+            kw.update({k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items() if k in _CONFIG_KEYS})
     if sample_size:
         kw["sample_size"] = sample_size
     vae = AutoencoderKLCausal3D(device=device, dtype=dtype, **kw)
@@ -24,5 +37,4 @@ def load_vae(vae_type: str = "884-16c-hy", vae_precision: str = "fp16", sample_s
         vae.load_state_dict(state_dict)
     vae.requires_grad_(False)
     vae.eval()
-    spatial_compression_ratio, time_compression_ratio = 8, 4
-    return vae, vae_path, spatial_compression_ratio, time_compression_ratio
+    return vae, vae_path, vae.config.spatial_compression_ratio, vae.config.time_compression_ratio

@@ -32,6 +32,12 @@ def parse_args():
     p.add_argument("--ulysses-degree", type=int, default=1)
     p.add_argument("--ring-degree", type=int, default=1)
     p.add_argument("--text-len", type=int, default=256)
+    p.add_argument("--dit-weight", default=None, help="reference-format DiT checkpoint: file or directory (inference.py:279-354); "
+                                                      "default: random-init weights")
+    p.add_argument("--load-key", default="module", help="key of the state dict inside a wrapped checkpoint (module | ema)")
+    p.add_argument("--model-base", default=None, help="root holding t2v_<resolution>/ when --dit-weight is a bare name")
+    p.add_argument("--model-resolution", default="540p")
+    p.add_argument("--vae-path", default=None, help="directory with the reference's VAE config.json + pytorch_model.pt")
     p.add_argument("--tiny", action="store_true", help="tiny DiT (d=256, 1+1 blocks) and reduced VAE: plumbing check")
     p.add_argument("--save-path", default="./results")
     return p.parse_args()
@@ -53,13 +59,23 @@ def main():
         raise ValueError("height/width must be multiples of 16 and (video_length - 1) a multiple of 4 (inference.py:571-586)")
     cfg = syn.tiny_config() if a.tiny else syn.DiTConfig()
     model = build_model(cfg, dev, seed=0)
-    if a.use_fp8:
+    if a.dit_weight or a.model_base:
+        # real weights: same order as the reference (inference.py:199-202): fp8 conversion (scales from <ckpt>_map.pt), then load
+        from hunyuanvideo_efficiency_amd import checkpoint
+        if a.use_fp8:
+            convert_fp8_linear(model, a.dit_weight, torch.bfloat16)
+        checkpoint.load_state_dict(a, model, a.model_base)
+    elif a.use_fp8:
         convert_fp8_linear(model, None, torch.bfloat16)
-    boc = (64, 64, 128, 128) if a.tiny else syn.VAE_BLOCK_OUT_CHANNELS
-    vae = AutoencoderKLCausal3D(block_out_channels=boc, device=dev)
-    with torch.no_grad():
-        for k, p in vae.state_dict().items():
-            p.copy_(syn.synth_param("vae." + k, tuple(p.shape), 0, dev).to(p.dtype))
+    if a.vae_path:
+        from hunyuanvideo_efficiency_amd.vae import load_vae
+        vae = load_vae(a.vae, a.vae_precision, vae_path=a.vae_path, device=dev)[0]
+    else:
+        boc = (64, 64, 128, 128) if a.tiny else syn.VAE_BLOCK_OUT_CHANNELS
+        vae = AutoencoderKLCausal3D(block_out_channels=boc, device=dev)
+        with torch.no_grad():
+            for k, p in vae.state_dict().items():
+                p.copy_(syn.synth_param("vae." + k, tuple(p.shape), 0, dev).to(p.dtype))
     sched = FlowMatchDiscreteScheduler(shift=a.flow_shift, reverse=a.flow_reverse, solver=a.flow_solver)
     pipe = HunyuanVideoPipeline(vae, model, sched, a)
     if a.ulysses_degree > 1:
