@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sp", action="store_true", help="N=1 only: run the sequence-parallel code path on a 1-rank RCCL group "
                     "(pack/unpack + self all-to-all + chunked QKV GEMMs) to price its overhead")
+    ap.add_argument("--ring-degree", type=int, default=1, help="N > 1: hybrid Ulysses x Ring with this ring degree (ulysses = N / ring); "
+                    "default 1 = pure Ulysses")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-by-`value`) VAE tiled decode of the same video")
     a = ap.parse_args()
 
@@ -113,7 +115,13 @@ def main():
     model = build_model(cfg, dev, seed=0)
     if world > 1 or a.force_sp:
         from hunyuanvideo_efficiency_amd.inference import parallelize_transformer_module
-        parallelize_transformer_module(model, dist.group.WORLD)
+        if a.ring_degree > 1:
+            from hunyuanvideo_efficiency_amd.inference import set_sequence_parallel_groups
+            assert world % a.ring_degree == 0
+            set_sequence_parallel_groups(world // a.ring_degree, a.ring_degree)
+            parallelize_transformer_module(model, None)
+        else:
+            parallelize_transformer_module(model, dist.group.WORLD)
     x, ts, tm, ts2 = syn.synth_dit_inputs(cfg, (T, H, W), s_txt, 11, seed=42, device=dev)
     ts = ts.to(torch.bfloat16)
     cos, sin = get_nd_rotary_pos_embed(cfg.rope_dim_list, [T, H // 2, W // 2], theta=256, use_real=True, device=dev)
@@ -199,7 +207,7 @@ def main():
             "dtype": "bf16", "data": "synthetic (hash-generated latents/text embeddings, random-init weights)",
             "config": {"workload": f"{a.workload}: latent 16x{T}x{H}x{W}, S_img={s_img}, S_txt={s_txt} (11 valid), "
                                    f"d={cfg.hidden_size}, heads={cfg.heads_num}, {cfg.mm_double_blocks_depth}+{cfg.mm_single_blocks_depth} blocks",
-                       "parallelism": ("single GPU" + (" (SP code path forced on a 1-rank group)" if a.force_sp else "")) if world == 1 else f"ulysses{world} (token-axis shard, RCCL all-to-all)"},
+                       "parallelism": ("single GPU" + (" (SP code path forced on a 1-rank group)" if a.force_sp else "")) if world == 1 else (f"ulysses{world} (token-axis shard, RCCL all-to-all)" if a.ring_degree == 1 else f"ulysses{world // a.ring_degree} x ring{a.ring_degree} (RCCL all-to-all + point-to-point K/V ring)")},
             "sec_per_video_50steps_denoise_only": 50 * ms_per_step / 1e3,
             "vae_tiled_decode_s": vae_s,
             "sec_per_video_50steps_plus_vae_decode": (50 * ms_per_step / 1e3 + vae_s) if vae_s is not None else None,

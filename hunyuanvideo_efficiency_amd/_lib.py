@@ -25,6 +25,9 @@ SIGNATURES = {
     "hv_timestep_embedding_bf16": [_p, _p, _i, _i, _f, _p],
     "hv_attn_fwd_bf16": [_p, _p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _f, _p, _l, _p],
     "hv_attn_workspace_bytes": [_i, _i, _i],
+    "hv_attn_partial_bf16": [_p, _p, _p, _l, _l, _l, _i, _i, _i, _i, _f, _p, _p, _i, _i, _i, _p],
+    "hv_attn_merge_bf16": [_p, _p, _p, _l, _i, _i, _i, _p],
+    "hv_attn_suggest_splits": [_i, _i, _i],
     "hv_patchify_f32_bf16": [_p, _p, _i, _i, _i, _i, _p],
     "hv_unpatchify_bf16": [_p, _p, _i, _i, _i, _i, _l, _p],
     "hv_euler_step_f32": [_p, _p, _f, _l, _p],

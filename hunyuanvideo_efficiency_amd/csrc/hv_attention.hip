@@ -43,6 +43,7 @@ struct AttnArgs {
     int n_splits, split_keys;
     float* part_o;      // [n_splits][n_q][n_heads][128]
     float* part_ml;     // [n_splits][n_q][n_heads][2]
+    int partial;        // 1: always leave the unnormalised partial (ring attention merges K/V chunks later), even unsplit
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v2(AttnArgs a) {
     }
 
     const float l_tot = half_swap_sum(l_run);
-    if (a.n_splits > 1) {   // partial result: O^T unnormalised (fp32) + (m, l); merged by attn_combine_kernel
+    if (a.n_splits > 1 || a.partial) {   // partial result: O^T unnormalised (fp32) + (m, l); merged by attn_combine_kernel
         const int qrow_p = q0 + lr;
         if (qrow_p < a.n_q) {
             const int64_t rowi = ((int64_t)blockIdx.y * a.n_q + qrow_p) * a.n_heads + head;
@@ -355,7 +356,7 @@ extern "C" int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     // Load balance: workgroups are equal-cost items on 256 CUs; with only a few rounds (e.g. 3 heads per rank under Ulysses-8:
     // 1395 items = 5.45 rounds -> 6) a partially filled last round costs a whole item.  Splitting the key range in two makes
     // the items half as long (2790 items = 10.9 -> 11 half-rounds = 5.5): taken when it shortens the makespan by > 3 %.
-    a.n_splits = 1; a.split_keys = n_kv; a.part_o = nullptr; a.part_ml = nullptr;
+    a.n_splits = 1; a.split_keys = n_kv; a.part_o = nullptr; a.part_ml = nullptr; a.partial = 0;
     {
         const int64_t nwg = (int64_t)a.n_qtiles * n_heads;
         const int ntile = (n_kv + KVT - 1) / KVT;
@@ -374,4 +375,56 @@ extern "C" int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
                                                                                            a.n_splits);
     }
     return hv_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ring attention building blocks: attention of the same queries against one K/V CHUNK at a time, each chunk leaving an
+// unnormalised partial (O fp32, running max m in the log2 domain, denominator l) in a slot; hv_attn_merge_bf16 folds all
+// slots into the normalised bf16 output.  Slot layout: part_o [n_slots][n_q][n_heads][128] fp32, part_ml [n_slots][n_q][n_heads][2].
+extern "C" int hv_attn_partial_bf16(const void* q, const void* k, const void* v, int64_t stride_q, int64_t stride_k, int64_t stride_v,
+                                    int n_q, int n_kv, int n_heads, int head_dim, float scale, void* part_o, void* part_ml,
+                                    int n_slots, int slot, int splits, hipStream_t stream) {
+    if (!q || !k || !v || !part_o || !part_ml || head_dim != D || n_heads <= 0 || n_q < 0 || n_kv <= 0 || (stride_q & 7) ||
+        (stride_k & 7) || (stride_v & 7) || (splits != 1 && splits != 2) || slot < 0 || slot + splits > n_slots)
+        return HV_ERR_ARG;
+    if (n_q == 0) return HV_OK;
+    const int ntile = (n_kv + KVT - 1) / KVT;
+    if (splits == 2 && ntile < 2) return HV_ERR_ARG;
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = nullptr;
+    a.sq = stride_q; a.sk = stride_k; a.sv = stride_v; a.so = 0;
+    a.n_q = n_q; a.n_kv = n_kv; a.n_heads = n_heads;
+    a.n_qtiles = (n_q + QTILE - 1) / QTILE;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    a.n_splits = splits;
+    a.split_keys = splits == 2 ? ((ntile + 1) / 2) * KVT : n_kv;
+    a.part_o = (float*)part_o + (int64_t)slot * n_q * n_heads * D;
+    a.part_ml = (float*)part_ml + (int64_t)slot * n_q * n_heads * 2;
+    a.partial = 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)attn_fwd_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
+            return HV_ERR_LAUNCH;
+        attr_set = true;
+    }
+    attn_fwd_kernel_v2<<<dim3((unsigned)(a.n_qtiles * n_heads), (unsigned)splits), dim3(512), ATT_LDS, stream>>>(a);
+    return hv_check_launch();
+}
+
+extern "C" int hv_attn_merge_bf16(const void* part_o, const void* part_ml, void* o, int64_t stride_o, int n_q, int n_heads, int n_slots,
+                                  hipStream_t stream) {
+    if (!part_o || !part_ml || !o || n_heads <= 0 || n_q < 0 || n_slots <= 0 || (stride_o & 3)) return HV_ERR_ARG;
+    if (n_q == 0) return HV_OK;
+    const int64_t total = (int64_t)n_q * n_heads * 32;
+    attn_combine_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>((const float*)part_o, (const float*)part_ml,
+                                                                                       (bf16_t*)o, stride_o, n_q, n_heads, n_slots);
+    return hv_check_launch();
+}
+
+// 1 or 2: whether halving the key range shortens the makespan of the (n_q/256 x n_heads)-workgroup grid on 256 CUs by > 3 %
+extern "C" int hv_attn_suggest_splits(int n_q, int n_kv, int n_heads) {
+    const int64_t nwg = (int64_t)((n_q + QTILE - 1) / QTILE) * n_heads;
+    const int ntile = (n_kv + KVT - 1) / KVT;
+    const double r1 = (double)((nwg + 255) / 256), r2 = 0.5 * (double)((2 * nwg + 255) / 256);
+    return (ntile >= 64 && r2 < 0.97 * r1) ? 2 : 1;
 }

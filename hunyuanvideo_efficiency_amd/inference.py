@@ -15,26 +15,54 @@ from .modules.posemb_layers import get_nd_rotary_pos_embed
 
 
 def init_distributed(ulysses_degree: int = 1, ring_degree: int = 1, backend: str = "nccl"):
-    """inference.py:157-176: WORLD_SIZE must equal ring*ulysses; this build implements pure Ulysses (ring 1)."""
-    if ring_degree != 1:
-        raise NotImplementedError("ring attention (--ring-degree > 1) is a SURVEY.md 8(f) 'next' row; use ulysses only")
+    """inference.py:157-176: WORLD_SIZE must equal ring*ulysses.  ring_degree > 1 builds the two process groups of the hybrid
+    scheme (Ulysses groups = runs of `ulysses_degree` consecutive ranks, ring groups = ranks with equal position in their
+    run - yunchang's `use_ulysses_low` order) and registers them as the defaults of UlyssesLongContextAttention."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == ulysses_degree * ring_degree, "number of GPUs should be equal to ring_size * ulysses_degree."
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, device_id=device if backend == "nccl" else None)
+    if world > 1:
+        set_sequence_parallel_groups(ulysses_degree, ring_degree)
     return device
 
 
-def parallelize_transformer_module(transformer, group=None, kernels=None):
+def set_sequence_parallel_groups(ulysses_degree: int, ring_degree: int):
+    """Every rank creates every group, in the same order (torch.distributed.new_group is collective)."""
+    rank = dist.get_rank()
+    if ring_degree == 1:
+        UlyssesLongContextAttention.set_sequence_parallel_group(None, None)
+        return None, None
+    ulysses_pg = ring_pg = None
+    for i in range(ring_degree):
+        ranks = list(range(i * ulysses_degree, (i + 1) * ulysses_degree))
+        g = dist.new_group(ranks)
+        if rank in ranks:
+            ulysses_pg = g
+    for j in range(ulysses_degree):
+        ranks = list(range(j, ulysses_degree * ring_degree, ulysses_degree))
+        g = dist.new_group(ranks)
+        if rank in ranks:
+            ring_pg = g
+    UlyssesLongContextAttention.set_sequence_parallel_group(ulysses_pg, ring_pg)
+    return ulysses_pg, ring_pg
+
+
+def parallelize_transformer_module(transformer, group=None, kernels=None, ulysses_group=None, ring_group=None):
     """Wrap transformer.forward as the reference's new_forward does (inference.py:45-104): pick the split axis
     (latent H if (H/2) % P == 0, else W), shard x and the RoPE tables, install the SP attention object on every
     block, run, all-gather the output along the split axis."""
     original_forward = transformer.forward
-    sp_attn = UlyssesLongContextAttention(group, kernels)
+    # `group`: the ranks the token axis is sharded over (None = WORLD = ulysses x ring); the attention object trades tokens for
+    # heads inside `ulysses_group` (default: registered default, else `group`) and rings K/V over `ring_group`
+    if ulysses_group is None and ring_group is None and UlyssesLongContextAttention._default_ring_group is None:
+        ulysses_group = group
+    sp_attn = UlyssesLongContextAttention(ulysses_group, kernels, ring_group)
 
     @functools.wraps(original_forward)
     def new_forward(x, t, text_states=None, text_mask=None, text_states_2=None, freqs_cos=None, freqs_sin=None,

@@ -36,25 +36,62 @@ class _HipKernels:
         from . import ops
         return ops.attn_fwd(q, k, v, out, heads)
 
+    # ring attention: per-chunk partials + merge
+    @staticmethod
+    def attn_partials(n_slots, n_q, heads, device):
+        from . import ops
+        return ops.AttnPartials(n_slots, n_q, heads, device)
+
+    @staticmethod
+    def attn_suggest_splits(n_q, n_kv, heads):
+        from . import ops
+        return ops.attn_suggest_splits(n_q, n_kv, heads)
+
+    @staticmethod
+    def attn_partial(q, k, v, parts, heads, splits):
+        from . import ops
+        return ops.attn_partial(q, k, v, parts, heads, splits)
+
+    @staticmethod
+    def attn_merge(parts, out):
+        from . import ops
+        return ops.attn_merge(parts, out)
+
 
 class UlyssesLongContextAttention:
-    """Constructible with no arguments like xFuserLongContextAttention(); uses the default (WORLD) group unless a
-    sequence-parallel group was registered with set_sequence_parallel_group()."""
+    """Constructible with no arguments like xFuserLongContextAttention(); uses the default (WORLD) group as the Ulysses
+    group unless groups were registered with set_sequence_parallel_group(ulysses_group, ring_group).
+
+    Hybrid Ulysses x Ring (xfuser `--ulysses-degree U --ring-degree R`, world = U*R; hyvideo/inference.py:157-176): the
+    all-to-alls run inside the Ulysses group (U ranks trade tokens for heads), after which a rank holds the tokens of its
+    Ulysses group for H/U heads; the K/V of the other R-1 Ulysses groups arrive over the ring group by point-to-point
+    send/recv (xGMI links are point-to-point, so a ring step IS one link), one hop per step, while the attention of the chunk
+    already here runs (hv_attn_partial_bf16); the per-chunk partials are folded by hv_attn_merge_bf16 (online softmax).
+    The joint (text) keys ride with the local chunk only, the joint queries sit at the rear of every rank's Q."""
 
     _default_group = None
+    _default_ring_group = None
 
-    def __init__(self, group=None, kernels=None):
+    def __init__(self, group=None, kernels=None, ring_group=None):
         self.group = group if group is not None else UlyssesLongContextAttention._default_group
+        self.ring_group = ring_group if ring_group is not None else UlyssesLongContextAttention._default_ring_group
         self.k = kernels or _HipKernels
         self._bufs = {}
+        self._parts = None
 
     @classmethod
-    def set_sequence_parallel_group(cls, group):
+    def set_sequence_parallel_group(cls, group, ring_group=None):
         cls._default_group = group
+        cls._default_ring_group = ring_group
 
     # ------------------------------------------------------------------ helpers
     def _world(self):
         return dist.get_world_size(self.group), dist.get_rank(self.group)
+
+    def _ring(self):
+        if self.ring_group is None:
+            return 1, 0
+        return dist.get_world_size(self.ring_group), dist.get_rank(self.ring_group)
 
     def _buf(self, name, shape, device):
         b = self._bufs.get(name)
@@ -63,19 +100,61 @@ class UlyssesLongContextAttention:
             self._bufs[name] = b
         return b
 
+    def _full_bufs(self, n_tot, w, device):
+        """q / k / v / o over all tokens of this rank's Ulysses group (+ joint rows at the rear) for its head group; K and V share
+        one allocation so a ring step ships them as two contiguous pieces."""
+        kv = self._buf("kvf", (2, n_tot, w), device)
+        self._bufs["kf"], self._bufs["vf"] = kv[0], kv[1]
+        return {"qf": self._buf("qf", (n_tot, w), device), "kf": kv[0], "vf": kv[1], "of": self._buf("of", (n_tot, w), device)}
+
+    def _attention(self, b, hp, s_u, n_j):
+        """Attention of this rank's queries (s_u group tokens + n_j joint rows) over ALL keys: local chunk (+ joint keys), then,
+        with a ring group, the chunks of the other Ulysses groups as they arrive."""
+        R, rr = self._ring()
+        qf, kf, vf, of = b["qf"], b["kf"], b["vf"], b["of"]
+        if R == 1:
+            self.k.attn_fwd(qf, kf, vf, of, hp)
+            return
+        n_q, w, dev = qf.shape[0], qf.shape[1], qf.device
+        nxt = dist.get_global_rank(self.ring_group, (rr + 1) % R)
+        prv = dist.get_global_rank(self.ring_group, (rr - 1) % R)
+        rot = [self._buf("ring_a", (2, s_u, w), dev), self._buf("ring_b", (2, s_u, w), dev)]
+        sp0 = self.k.attn_suggest_splits(n_q, s_u + n_j, hp)
+        sp = self.k.attn_suggest_splits(n_q, s_u, hp)
+        n_slots = sp0 + (R - 1) * sp
+        p = self._parts
+        if p is None or (p.n_slots, p.n_q, p.n_heads) != (n_slots, n_q, hp) or p.o.device != dev:
+            p = self._parts = self.k.attn_partials(n_slots, n_q, hp, dev)
+        p.used = 0
+        cur_k, cur_v, n_cur = kf, vf, s_u + n_j
+        for t in range(R):
+            works = []
+            if t + 1 < R:
+                dst = rot[t % 2]
+                works = dist.batch_isend_irecv([
+                    dist.P2POp(dist.isend, cur_k[:s_u], nxt, self.ring_group), dist.P2POp(dist.isend, cur_v[:s_u], nxt, self.ring_group),
+                    dist.P2POp(dist.irecv, dst[0], prv, self.ring_group), dist.P2POp(dist.irecv, dst[1], prv, self.ring_group)])
+            # the chunk already here is attended while the next one crosses the link
+            self.k.attn_partial(qf, cur_k[:n_cur], cur_v[:n_cur], p, hp, sp0 if t == 0 else sp)
+            for wk in works:
+                wk.wait()
+            if t + 1 < R:
+                cur_k, cur_v, n_cur = dst[0], dst[1], s_u
+        self.k.attn_merge(p, of)
+
     def _core(self, q_src, k_src, v_src, ld_src, jq, jk, jv, ld_j, s_loc, n_j, heads, out, ld_out):
         """q_src/k_src/v_src: tensors whose data_ptr is (row 0, head 0) of the local image rows, row stride ld_src;
         jq/jk/jv: same for the n_j joint (text) rows, row stride ld_j; out: destination [s_loc + n_j rows, heads*128]
         with row stride ld_out."""
         P, rank = self._world()
         if heads % P != 0:
-            raise ValueError(f"Ulysses degree {P} must divide the head count {heads} (hybrid ring attention is not built)")
+            raise ValueError(f"Ulysses degree {P} must divide the head count {heads} (put the remaining factor on --ring-degree)")
         hp = heads // P
         w = hp * 128
         dev = q_src.device
         s_img = P * s_loc
         n_tot = s_img + n_j
-        full = {n: self._buf(n, (n_tot, w), dev) for n in ("qf", "kf", "vf", "of")}
+        full = self._full_bufs(n_tot, w, dev)
         send = self._buf("send", (P * s_loc, w), dev)
         for name, src, j in (("qf", q_src, jq), ("kf", k_src, jk), ("vf", v_src, jv)):
             # pack: send[p][r][:] = src[r][p*w : (p+1)*w]
@@ -84,7 +163,7 @@ class UlyssesLongContextAttention:
             if n_j:
                 # joint rows at the rear, my head group only: full[s_img + r][:] = j[r][rank*w : (rank+1)*w]
                 self.k.copy3d(j[:, rank * w:], full[name][s_img:], 1, n_j, w, 0, ld_j, 0, w)
-        self.k.attn_fwd(full["qf"], full["kf"], full["vf"], full["of"], hp)
+        self._attention(full, hp, s_img, n_j)
         recv = self._buf("recv", (P * s_loc, w), dev)
         dist.all_to_all_single(recv, full["of"][:s_img], group=self.group)
         # unpack: out[r][p*w + c] = recv[p][r][c]
@@ -102,12 +181,11 @@ class UlyssesLongContextAttention:
     def begin(self, s_loc: int, n_j: int, heads: int, device):
         P, rank = self._world()
         if heads % P != 0:
-            raise ValueError(f"Ulysses degree {P} must divide the head count {heads} (hybrid ring attention is not built)")
+            raise ValueError(f"Ulysses degree {P} must divide the head count {heads} (put the remaining factor on --ring-degree)")
         w = (heads // P) * 128
         self._geo = (P, rank, s_loc, n_j, heads, w)
         n_tot = P * s_loc + n_j
-        for n in ("qf", "kf", "vf", "of"):
-            self._buf(n, (n_tot, w), device)
+        self._full_bufs(n_tot, w, device)
         self._works = []
 
     def send(self, which: str, src: torch.Tensor, ld_src: int, joint: Optional[torch.Tensor], ld_j: int):
@@ -128,7 +206,7 @@ class UlyssesLongContextAttention:
         self._works = []
         b = self._bufs
         s_img = P * s_loc
-        self.k.attn_fwd(b["qf"], b["kf"], b["vf"], b["of"], heads // P)
+        self._attention(b, heads // P, s_img, n_j)
         recv = self._buf("recv", (s_img, w), out.device)
         dist.all_to_all_single(recv, b["of"][:s_img], group=self.group)
         self.k.copy3d(recv, out, P, s_loc, w, s_loc * w, w, w, ld_out)

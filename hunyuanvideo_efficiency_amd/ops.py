@@ -169,6 +169,51 @@ def attn_fwd(q, k, v, out, n_heads: int, scale: Optional[float] = None, kv_split
     return out
 
 
+class AttnPartials:
+    """Slots of unnormalised attention partials (ring attention): part_o fp32 [n_slots, n_q, H, 128], part_ml [n_slots, n_q, H, 2]."""
+
+    def __init__(self, n_slots: int, n_q: int, n_heads: int, device):
+        self.n_slots, self.n_q, self.n_heads = n_slots, n_q, n_heads
+        self.o = torch.empty(n_slots, n_q, n_heads, 128, dtype=torch.float32, device=device)
+        self.ml = torch.empty(n_slots, n_q, n_heads, 2, dtype=torch.float32, device=device)
+        self.used = 0
+
+
+def attn_suggest_splits(n_q: int, n_kv: int, n_heads: int) -> int:
+    return int(_lib.load().hv_attn_suggest_splits(n_q, n_kv, n_heads))
+
+
+def attn_partial(q, k, v, parts: AttnPartials, n_heads: int, splits: int = 1, scale: Optional[float] = None):
+    """Attention of q against ONE K/V chunk; appends `splits` slots to `parts` (hv_attn_partial_bf16)."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, BF16, nm)
+        assert t.dim() == 2
+    n_q, n_kv = q.shape[0], k.shape[0]
+    assert v.shape[0] == n_kv and n_q == parts.n_q and n_heads == parts.n_heads and parts.used + splits <= parts.n_slots
+    if scale is None:
+        scale = 128 ** -0.5
+    prof = PROFILE_ATTN
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().hv_attn_partial_bf16(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), n_q, n_kv, n_heads,
+                                                128, scale, _ptr(parts.o), _ptr(parts.ml), parts.n_slots, parts.used, splits,
+                                                _stream()), "hv_attn_partial_bf16")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, n_q, n_kv, n_heads))
+    parts.used += splits
+
+
+def attn_merge(parts: AttnPartials, out):
+    """Fold the used slots into normalised bf16 rows out[n_q, >= H*128] (hv_attn_merge_bf16)."""
+    _chk(out, BF16, "out")
+    assert out.dim() == 2 and out.shape[0] == parts.n_q and parts.used >= 1
+    _lib.check(_lib.load().hv_attn_merge_bf16(_ptr(parts.o), _ptr(parts.ml), _ptr(out), out.stride(0), parts.n_q, parts.n_heads,
+                                              parts.used, _stream()), "hv_attn_merge_bf16")
+    return out
+
+
 def patchify(x_f32, out=None):
     """x:[C,T,H,W] fp32 -> [T*(H/2)*(W/2), C*4] bf16"""
     _chk(x_f32, torch.float32, "x")

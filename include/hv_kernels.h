@@ -81,6 +81,22 @@ int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64
 /* bytes of scratch hv_attn_fwd_bf16 can use for the KV split (returned as int64). */
 int64_t hv_attn_workspace_bytes(int n_q, int n_kv, int n_heads);
 
+/* Ring attention (hybrid Ulysses x Ring, xfuser `ring_degree > 1`: hyvideo/inference.py:171-175, call site
+ * modules/attenion.py:169-180): the queries of one rank against ONE K/V chunk.  Leaves the unnormalised partial in slot(s)
+ * [slot, slot+splits) of caller-owned buffers part_o = float[n_slots][n_q][n_heads][128], part_ml = float[n_slots][n_q][n_heads][2]
+ * (running max in the log2 domain, denominator).  splits = 1 | 2: 2 halves the key range over two workgroup sets (load balance,
+ * see hv_attn_suggest_splits) and fills two slots. */
+int hv_attn_partial_bf16(const void* q, const void* k, const void* v, int64_t stride_q, int64_t stride_k, int64_t stride_v,
+                         int n_q, int n_kv, int n_heads, int head_dim, float scale, void* part_o, void* part_ml,
+                         int n_slots, int slot, int splits, hipStream_t stream);
+
+/* Online-softmax merge of all n_slots partials: o = sum_s O_s 2^(m_s-m) / sum_s l_s 2^(m_s-m), written as bf16 rows. */
+int hv_attn_merge_bf16(const void* part_o, const void* part_ml, void* o, int64_t stride_o, int n_q, int n_heads, int n_slots,
+                       hipStream_t stream);
+
+/* 1 or 2: whether splitting the key range shortens the makespan of this launch shape on 256 CUs. */
+int hv_attn_suggest_splits(int n_q, int n_kv, int n_heads);
+
 /* K10 gather: fp32 latent [C,T,H,W] -> bf16 patch rows [T*(H/2)*(W/2), C*4] (embed_layers.py:40-59). */
 int hv_patchify_f32_bf16(const float* x, void* A, int C, int T, int H, int W, hipStream_t stream);
 

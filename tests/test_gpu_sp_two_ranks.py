@@ -47,6 +47,46 @@ def _stage_collectives_through_host():
 
     dist.all_to_all_single, dist.all_gather_into_tensor, dist.all_gather = a2a, ag_into, ag
 
+    real_batch = dist.batch_isend_irecv
+
+    class _RecvDone:
+        def __init__(self, work, host, dev):
+            self.work, self.host, self.dev = work, host, dev
+
+        def wait(self):
+            self.work.wait()
+            self.dev.copy_(self.host.view(self.dev.shape))
+            return True
+
+    def batch(ops):
+        """ring hops: sends leave from a host copy, receives land in a host buffer and are copied to the card on wait()"""
+        host_ops, recvs = [], []
+        for op in ops:
+            if op.op is dist.isend:
+                host_ops.append(dist.P2POp(dist.isend, op.tensor.detach().cpu().contiguous(), op.peer, op.group))
+            else:
+                h = torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+                host_ops.append(dist.P2POp(dist.irecv, h, op.peer, op.group))
+                recvs.append((len(host_ops) - 1, h, op.tensor))
+        works = real_batch(host_ops)
+        out = []
+        if len(works) == len(host_ops):
+            rmap = {i: (h, d) for i, h, d in recvs}
+            for i, wk in enumerate(works):
+                out.append(_RecvDone(wk, *rmap[i]) if i in rmap else wk)
+        else:       # coalesced into one work object
+            class _All:
+                def wait(self_inner):
+                    for wk in works:
+                        wk.wait()
+                    for _, h, d in recvs:
+                        d.copy_(h.view(d.shape))
+                    return True
+            out = [_All()]
+        return out
+
+    dist.batch_isend_irecv = batch
+
 
 def _worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
@@ -135,6 +175,55 @@ def _vae_worker(rank, world, port, outdir):
         with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:
             f.write(results.get(rank, "FAIL: no result"))
         dist.destroy_process_group()
+
+
+def _ring_worker(rank, world, port, outdir, U, R):
+    """Hybrid Ulysses x Ring with the real HIP kernels (hv_attn_partial_bf16 / hv_attn_merge_bf16 + the exchange kernels)."""
+    sys.path.insert(0, ROOT)
+    results = {}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0")
+    try:
+        torch.cuda.set_device(0)
+        from hunyuanvideo_efficiency_amd import selftest, synthetic as syn
+        from hunyuanvideo_efficiency_amd.inference import init_distributed, parallelize_transformer_module
+        from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
+        init_distributed(U, R, backend="gloo")
+        _stage_collectives_through_host()
+        cfg = syn.DiTConfig(hidden_size=512, heads_num=4, mm_double_blocks_depth=1, mm_single_blocks_depth=2)
+        for thw, txt_len, n_valid in (((5, 8 * world, 16), 32, 11), ((3, 8 * world, 24), 16, 0)):
+            base_model = selftest.build_model(cfg, "cuda")
+            sp_model = selftest.build_model(cfg, "cuda")
+            parallelize_transformer_module(sp_model, None)
+            x, ts, tm, ts2 = syn.synth_dit_inputs(cfg, thw, txt_len, n_valid, seed=1)
+            T, H, W = thw
+            cos, sin = get_nd_rotary_pos_embed(cfg.rope_dim_list, [T, H // 2, W // 2], theta=256, use_real=True)
+            kw = dict(text_states=ts.to(torch.bfloat16).cuda(), text_mask=tm.cuda(), text_states_2=ts2.cuda(),
+                      freqs_cos=cos.cuda(), freqs_sin=sin.cuda(), guidance=torch.tensor([6016.0], device="cuda"), return_dict=True)
+            t = torch.tensor([997.093], device="cuda")
+            with torch.no_grad():
+                base = base_model(x.cuda(), t, **kw)["x"].float().cpu()
+                out = sp_model(x.cuda(), t, **kw)["x"].float().cpu()
+            torch.cuda.synchronize()
+            err = float((out - base).abs().max() / base.abs().max())
+            assert err < 1e-2, (U, R, thw, n_valid, err)
+        results[rank] = "ok"
+    except Exception:  # noqa: BLE001
+        import traceback
+        results[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:
+            f.write(results.get(rank, "FAIL: no result"))
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("U,R", [(1, 2), (2, 2), (1, 3)])
+def test_hybrid_ulysses_ring_forward_on_one_card(U, R, tmp_path):
+    world = U * R
+    port = 29850 + (os.getpid() % 40) + 4 * U + R
+    mp.start_processes(_ring_worker, args=(world, port, str(tmp_path), U, R), nprocs=world, join=True, start_method="forkserver")
+    results = {r: open(tmp_path / f"rank{r}.txt").read() for r in range(world)}
+    assert all(v == "ok" for v in results.values()), results
 
 
 @pytest.mark.parametrize("world", [2, 3])

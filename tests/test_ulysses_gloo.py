@@ -31,6 +31,48 @@ class CpuKernelDouble:
         return out
 
 
+    # ---- ring attention doubles: the same partial format as hv_attn_partial_bf16 / hv_attn_merge_bf16 (log2-domain max)
+    class _Parts:
+        def __init__(self, n_slots, n_q, heads):
+            self.n_slots, self.n_q, self.n_heads, self.used = n_slots, n_q, heads, 0
+            self.o = torch.zeros(n_slots, n_q, heads, 128)
+            self.ml = torch.zeros(n_slots, n_q, heads, 2)
+
+    @staticmethod
+    def attn_partials(n_slots, n_q, heads, device):
+        return CpuKernelDouble._Parts(n_slots, n_q, heads)
+
+    @staticmethod
+    def attn_suggest_splits(n_q, n_kv, heads):
+        return 2 if n_kv >= 128 else 1          # exercise both slot counts
+
+    @staticmethod
+    def attn_partial(q, k, v, parts, heads, splits):
+        n_q, n_kv = q.shape[0], k.shape[0]
+        assert parts.used + splits <= parts.n_slots and q.shape[1] == heads * 128 == k.shape[1] == v.shape[1]
+        qh = q.float().reshape(n_q, heads, 128).transpose(0, 1)
+        bounds = [0, n_kv] if splits == 1 else [0, ((n_kv + 63) // 64 + 1) // 2 * 64, n_kv]
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            kh = k[lo:hi].float().reshape(hi - lo, heads, 128).transpose(0, 1)
+            vh = v[lo:hi].float().reshape(hi - lo, heads, 128).transpose(0, 1)
+            s = qh @ kh.transpose(1, 2) * (128 ** -0.5 * 1.4426950408889634)
+            m = s.max(-1, keepdim=True).values
+            pr = torch.exp2(s - m)
+            parts.o[parts.used] = (pr.to(torch.bfloat16).float() @ vh).transpose(0, 1)
+            parts.ml[parts.used, :, :, 0] = m[..., 0].transpose(0, 1)
+            parts.ml[parts.used, :, :, 1] = pr.sum(-1).transpose(0, 1)
+            parts.used += 1
+
+    @staticmethod
+    def attn_merge(parts, out):
+        o, ml = parts.o[:parts.used], parts.ml[:parts.used]
+        m = ml[..., 0].max(0).values
+        wgt = torch.exp2(ml[..., 0] - m)
+        acc = (o * wgt[..., None]).sum(0) / (ml[..., 1] * wgt).sum(0)[..., None]
+        out[:, :parts.n_heads * 128] = acc.reshape(parts.n_q, -1).to(torch.bfloat16)
+        return out
+
+
 def _worker(rank, world, port, results):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
