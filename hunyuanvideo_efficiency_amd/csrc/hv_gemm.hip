@@ -65,6 +65,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     // conv mode (ksz = 3): output grid cT x cH x cW, source tensor sT x sH x sW (differs when upsampling), cin per tap
     int cT, cH, cW, sT, sH, sW, up_t, up_hw, cin;
+    int mt, mh, mw, bH, bW;   // strided conv: source coordinate = output coordinate * m; bH/bW: extent the index is clamped to
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -113,10 +114,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         const int row = i * 64 + srow;
         const int ar = min(m0 + row, g.M - 1);  // clamp: tails read valid rows
         if (CONV) {
-            vw[i] = ar % g.cW;
+            vw[i] = (ar % g.cW) * g.mw;
             const int th = ar / g.cW;
-            vh[i] = th % g.cH;
-            vt[i] = th / g.cH;
+            vh[i] = (th % g.cH) * g.mh;
+            vt[i] = (th / g.cH) * g.mt;
             a_src[i] = g.A + ((scp ^ swz_a(row)) << 3);
         } else {
             a_src[i] = g.A + (int64_t)ar * g.lda + ((scp ^ swz_a(row)) << 3);
@@ -139,8 +140,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int ti = max(vt[i] + dt - 2, 0);
-                int hi = min(max(vh[i] + dh - 1, 0), g.cH - 1);
-                int wi = min(max(vw[i] + dw - 1, 0), g.cW - 1);
+                int hi = min(max(vh[i] + dh - 1, 0), g.bH - 1);
+                int wi = min(max(vw[i] + dw - 1, 0), g.bW - 1);
                 if (g.up_t) ti = ti == 0 ? 0 : 1 + ((ti - 1) >> 1);
                 hi >>= g.up_hw;
                 wi >>= g.up_hw;
@@ -344,5 +345,26 @@ extern "C" int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_ta
     if (rc != HV_OK) return rc;
     g.cT = T; g.cH = H; g.cW = W; g.cin = Cin; g.up_t = up_t; g.up_hw = up_hw;
     g.sT = up_t ? (T + 1) / 2 : T; g.sH = H >> up_hw; g.sW = W >> up_hw;
+    g.mt = g.mh = g.mw = 1; g.bH = H; g.bW = W;
+    return launch<F16T, true>(g, stream);
+}
+
+extern "C" int hv_conv3d_causal_strided_f16(const void* x, int64_t ldx, const void* w_taps, const void* bias, void* out, int64_t ldo,
+                                            int sT, int sH, int sW, int Cin, int Cout, int stride_t, int stride_h, int stride_w,
+                                            hipStream_t stream) {
+    // DownsampleCausal3D: the same replicate/causal padding, then Conv3d with stride (1|2 per axis).  Source index of output
+    // voxel (t,h,w), tap (dt,dh,dw): (t*st + dt - 2, h*sh + dh - 1, w*sw + dw - 1), clamped into the source grid.
+    if (sT <= 0 || sH <= 0 || sW <= 0 || Cin < 64 || (Cin % 64) || Cout <= 0 || stride_t < 1 || stride_t > 2 || stride_h < 1 ||
+        stride_h > 2 || stride_w < 1 || stride_w > 2)
+        return HV_ERR_ARG;
+    const int T = (sT - 1) / stride_t + 1, H = (sH - 1) / stride_h + 1, W = (sW - 1) / stride_w + 1;
+    if ((int64_t)sT * sH * sW > 0x7fffffff) return HV_ERR_ARG;
+    GemmArgs g;
+    int rc = fill_common(g, x, ldx, w_taps, (int64_t)27 * Cin, bias, T * H * W, Cout, 27 * Cin, out, ldo, 0, 0, nullptr, 0, 0,
+                         nullptr, nullptr, 0);
+    if (rc != HV_OK) return rc;
+    g.cT = T; g.cH = H; g.cW = W; g.cin = Cin; g.up_t = 0; g.up_hw = 0;
+    g.sT = sT; g.sH = sH; g.sW = sW;
+    g.mt = stride_t; g.mh = stride_h; g.mw = stride_w; g.bH = sH; g.bW = sW;
     return launch<F16T, true>(g, stream);
 }

@@ -227,6 +227,40 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const uint16_t* __rest
 
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Temporal resampling of a channels-last activation [T, HW, C] (the fork's "t_ops": unet_causal_3d_blocks.py:657-672,
+// 764-783,884-907).  mode 0: replicate-pad k-1 frames in front, then average k frames with stride s (avg_pool3d (k,1,1)/(s,1,1),
+// fp32 accumulation, one fp16 rounding); mode 1: nearest-neighbour repeat of every frame `s` times (F.interpolate (s,1,1)).
+__global__ __launch_bounds__(256) void temporal_resample_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
+                                                                 int64_t ldo, int t_out, int64_t hw, int c8, int mode, int k, int s) {
+    const int64_t total = (int64_t)t_out * hw * c8;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c8);
+        const int64_t row = idx / c8, p = row % hw;
+        const int t = (int)(row / hw);
+        const uint16_t* src = x + p * ldx + c * 8;
+        uint16_t* dst = out + row * ldo + c * 8;
+        if (mode == 1) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src + (int64_t)(t / s) * hw * ldx);
+        } else {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < k; ++i) {
+                const int ti = max(t * s + i - (k - 1), 0);
+                const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)ti * hw * ldx);
+                const _Float16* h = reinterpret_cast<const _Float16*>(&v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)h[j];
+            }
+            uint4 o;
+            _Float16* oh = reinterpret_cast<_Float16*>(&o);
+            const float inv = 1.0f / (float)k;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) oh[j] = (_Float16)(acc[j] * inv);
+            *reinterpret_cast<uint4*>(dst) = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int hv_groupnorm_affine_f16(const void* x, int64_t ldx, int64_t M, int C, int groups, float eps, const void* weight,
@@ -300,5 +334,17 @@ extern "C" int hv_copy4d_16b(const void* src, const int64_t* src_strides, void* 
 extern "C" int hv_vae_postprocess_f16_f32(const void* x, float* out, int64_t n, hipStream_t stream) {
     if (!x || !out || n <= 0) return HV_ERR_ARG;
     postprocess_kernel<<<dim3(grid_for(n)), dim3(256), 0, stream>>>((const uint16_t*)x, out, n);
+    return hv_check_launch();
+}
+
+extern "C" int hv_temporal_resample_f16(const void* x, int64_t ldx, void* out, int64_t ldo, int T_in, int64_t HW, int C, int mode,
+                                        int k, int s, hipStream_t stream) {
+    if (!x || !out || T_in <= 0 || HW <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldo & 7) || s < 1 || (mode != 0 && mode != 1) ||
+        (mode == 0 && k < 1))
+        return HV_ERR_ARG;
+    const int t_out = mode == 1 ? T_in * s : (T_in - 1) / s + 1;
+    const int64_t total = (int64_t)t_out * HW * (C / 8);
+    temporal_resample_kernel<<<dim3(grid_for(total)), dim3(256), 0, stream>>>((const uint16_t*)x, ldx, (uint16_t*)out, ldo, t_out, HW, C / 8,
+                                                                             mode, k, s);
     return hv_check_launch();
 }

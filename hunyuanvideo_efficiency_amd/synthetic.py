@@ -225,6 +225,57 @@ def vae_decoder_param_shapes(block_out_channels=VAE_BLOCK_OUT_CHANNELS, latent_c
     return t
 
 
-def synth_vae_state_dict(block_out_channels=VAE_BLOCK_OUT_CHANNELS, seed: int = 0, device="cpu", dtype=torch.float32):
-    return {k: synth_param("vae." + k, shp, seed, device).to(dtype)
-            for k, shp in vae_decoder_param_shapes(block_out_channels).items()}
+def vae_encoder_param_shapes(block_out_channels=VAE_BLOCK_OUT_CHANNELS, latent_channels: int = 16, in_channels: int = 3,
+                             layers_per_block: int = 2) -> Dict[str, Tuple[int, ...]]:
+    """State-dict layout of AutoencoderKLCausal3D's encode side (vae/vae.py:32-113: conv_in, 4 DownEncoderBlockCausal3D with
+    `downsamplers.0.conv.conv` where the block downsamples, mid block, conv_norm_out, conv_out -> 2*latent; quant_conv
+    autoencoder_kl_causal_3d.py:110-113); checked against the imported reference by tools/make_golden_vae_enc.py."""
+    t: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(name, co, ci, k):
+        t[name + ".weight"] = (co, ci, k, k, k)
+        t[name + ".bias"] = (co,)
+
+    def norm(name, c):
+        t[name + ".weight"] = (c,)
+        t[name + ".bias"] = (c,)
+
+    def resnet(pre, ci, co):
+        norm(pre + "norm1", ci)
+        conv(pre + "conv1.conv", co, ci, 3)
+        norm(pre + "norm2", co)
+        conv(pre + "conv2.conv", co, co, 3)
+        if ci != co:
+            conv(pre + "conv_shortcut.conv", co, ci, 1)
+
+    conv("encoder.conv_in.conv", block_out_channels[0], in_channels, 3)
+    nb = len(block_out_channels)
+    prev = block_out_channels[0]
+    for i, oc in enumerate(block_out_channels):
+        for j in range(layers_per_block):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}.", prev if j == 0 else oc, oc)
+        spatial = i < 3
+        temporal = (i >= nb - 1 - 2) and (i != nb - 1)
+        if spatial or temporal:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv.conv", oc, oc, 3)
+        prev = oc
+    top = block_out_channels[-1]
+    resnet("encoder.mid_block.resnets.0.", top, top)
+    a = "encoder.mid_block.attentions.0."
+    norm(a + "group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        t[a + n + ".weight"] = (top, top)
+        t[a + n + ".bias"] = (top,)
+    resnet("encoder.mid_block.resnets.1.", top, top)
+    norm("encoder.conv_norm_out", top)
+    conv("encoder.conv_out.conv", 2 * latent_channels, top, 3)
+    conv("quant_conv", 2 * latent_channels, 2 * latent_channels, 1)
+    return t
+
+
+def synth_vae_state_dict(block_out_channels=VAE_BLOCK_OUT_CHANNELS, seed: int = 0, device="cpu", dtype=torch.float32,
+                         encoder: bool = False):
+    shapes = dict(vae_decoder_param_shapes(block_out_channels))
+    if encoder:
+        shapes.update(vae_encoder_param_shapes(block_out_channels))
+    return {k: synth_param("vae." + k, shp, seed, device).to(dtype) for k, shp in shapes.items()}

@@ -57,6 +57,37 @@ def conv3d_causal(x, w_taps, bias, T: int, H: int, W: int, cin: int, cout: int, 
     return out
 
 
+def conv3d_causal_strided(x, w_taps, bias, sT: int, sH: int, sW: int, cin: int, cout: int, stride=(1, 1, 1)):
+    """DownsampleCausal3D conv: x channels-last [sT*sH*sW, >=cin] -> ([T*H*W, cout] fp16, T, H, W)."""
+    _chk(x, F16, "x"), _chk(w_taps, F16, "w_taps")
+    assert w_taps.is_contiguous() and w_taps.numel() == cout * 27 * cin, (w_taps.shape, cout, cin)
+    st, sh, sw = (int(v) for v in stride)
+    T, H, W = (sT - 1) // st + 1, (sH - 1) // sh + 1, (sW - 1) // sw + 1
+    out = torch.empty(T * H * W, cout, dtype=F16, device=x.device)
+    _lib.check(_lib.load().hv_conv3d_causal_strided_f16(_ptr(x), x.stride(0), _ptr(w_taps), _ptr(bias), _ptr(out), out.stride(0),
+                                                        sT, sH, sW, cin, cout, st, sh, sw, _stream()), "hv_conv3d_causal_strided_f16")
+    return out, T, H, W
+
+
+def temporal_avg_pool(x, T: int, HW: int, k: int, s: int):
+    """t_ops pool: replicate-pad k-1 frames in front + avg over k frames, stride s.  x [T*HW, C] -> ([T'*HW, C], T')."""
+    _chk(x, F16, "x")
+    t_out = (T - 1) // s + 1
+    out = torch.empty(t_out * HW, x.shape[1], dtype=F16, device=x.device)
+    _lib.check(_lib.load().hv_temporal_resample_f16(_ptr(x), x.stride(0), _ptr(out), out.stride(0), T, HW, x.shape[1], 0, k, s,
+                                                    _stream()), "hv_temporal_resample_f16")
+    return out, t_out
+
+
+def temporal_nearest_up(x, T: int, HW: int, s: int):
+    """t_ops interp: every frame repeated s times (F.interpolate nearest along T).  x [T*HW, C] -> ([T*s*HW, C], T*s)."""
+    _chk(x, F16, "x")
+    out = torch.empty(T * s * HW, x.shape[1], dtype=F16, device=x.device)
+    _lib.check(_lib.load().hv_temporal_resample_f16(_ptr(x), x.stride(0), _ptr(out), out.stride(0), T, HW, x.shape[1], 1, 1, s,
+                                                    _stream()), "hv_temporal_resample_f16")
+    return out, T * s
+
+
 _gn_ws = {}
 
 

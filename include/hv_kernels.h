@@ -143,6 +143,19 @@ int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_taps, const v
                          int T, int H, int W, int Cin, int Cout, int up_t, int up_hw, const void* res,
                          int64_t ld_res, hipStream_t stream);
 
+/* DownsampleCausal3D (VAE encoder, unet_causal_3d_blocks.py:185-247): the same padding as hv_conv3d_causal_f16, then the 3x3x3
+ * conv with stride 1|2 per axis (the fork's t_ops `downsample_stride` override, :737-742, changes these strides).
+ * x: source [sT,sH,sW,Cin]; out: [T*H*W, Cout] with T = (sT-1)/stride_t + 1, H = (sH-1)/stride_h + 1, W likewise. */
+int hv_conv3d_causal_strided_f16(const void* x, int64_t ldx, const void* w_taps, const void* bias, void* out, int64_t ldo,
+                                 int sT, int sH, int sW, int Cin, int Cout, int stride_t, int stride_h, int stride_w,
+                                 hipStream_t stream);
+
+/* The fork's temporal ops on a channels-last activation x[T_in][HW][C] (unet_causal_3d_blocks.py:657-672,764-783,884-907).
+ * mode 0: F.pad(replicate, k-1 frames in front) + F.avg_pool3d((k,1,1), stride (s,1,1)) -> T_out = (T_in-1)/s + 1;
+ * mode 1: F.interpolate(scale_factor=(s,1,1), mode="nearest") -> T_out = T_in*s.  C % 8 == 0. */
+int hv_temporal_resample_f16(const void* x, int64_t ldx, void* out, int64_t ldo, int T_in, int64_t HW, int C, int mode,
+                             int k, int s, hipStream_t stream);
+
 /* K16 pass 1+2: GroupNorm statistics (nn.GroupNorm(32, C, eps 1e-6, affine), unet_causal_3d_blocks.py:302,323) folded
  * into a per-channel affine: affine_out[2c] = rstd_g*w[c], affine_out[2c+1] = b[c] - mean_g*rstd_g*w[c].
  * partial_ws: caller workspace of partial_ws_floats floats (>= 2*C; 2*C*1024 for full parallelism). */
