@@ -1,8 +1,9 @@
 """AutoencoderKLCausal3D - decode side - on the MI355X kernels, with the reference's call surface
 (hyvideo/vae/autoencoder_kl_causal_3d.py: decode(z, return_dict, generator)[0], enable_tiling(), .config.*, .dtype)
 and the reference's state-dict key names for `decoder.*` and `post_quant_conv.*` (vae/vae.py:139-226,
-vae/unet_causal_3d_blocks.py).  The encoder is out of scope for the denoise+decode hot path;
-checkpoint keys under `encoder.` / `quant_conv.` are ignored on load.
+vae/unet_causal_3d_blocks.py).  The encode half (EncoderCausal3D, quant_conv, the posterior, tiled
+encode, forward(), and the fork's temporal-op hooks of t_ops_config.json on both halves) is built with `with_encoder=True`;
+without it checkpoint keys under `encoder.` / `quant_conv.` are ignored on load.
 
 Execution model: activations are fp16 CHANNELS-LAST ([T*H*W voxels, C]) so that
   * CausalConv3d is an implicit GEMM whose A rows are contiguous channel vectors (replicate padding = index clamp,
@@ -43,13 +44,57 @@ def _build_tree(root: nn.Module, shapes: Dict[str, Tuple[int, ...]], device, dty
         mod.register_parameter(parts[-1], nn.Parameter(torch.empty(*shp, device=device, dtype=dtype), requires_grad=False))
 
 
+class DiagonalGaussianDistribution:
+    """vae/vae.py:297-358 with the reference's attribute and method names.  The posterior's parameters are a few hundred KB
+    (the latent); its elementwise arithmetic is torch tensor math on the device that holds `parameters`, not a kernel."""
+
+    def __init__(self, parameters: torch.Tensor, deterministic: bool = False):
+        if parameters.ndim == 3:
+            dim = 2
+        elif parameters.ndim in (4, 5):
+            dim = 1
+        else:
+            raise NotImplementedError
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=dim)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if self.deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.parameters.device, dtype=self.parameters.dtype)
+        return self.mean + self.std * noise
+
+    def kl(self, other: "DiagonalGaussianDistribution" = None) -> torch.Tensor:
+        if self.deterministic:
+            return torch.Tensor([0.0])
+        dims = list(range(1, self.mean.ndim))
+        if other is None:
+            return 0.5 * torch.sum(torch.pow(self.mean, 2) + self.var - 1.0 - self.logvar, dim=dims)
+        return 0.5 * torch.sum(torch.pow(self.mean - other.mean, 2) / other.var + self.var / other.var - 1.0 - self.logvar
+                               + other.logvar, dim=dims)
+
+    def nll(self, sample: torch.Tensor, dims=(1, 2, 3)) -> torch.Tensor:
+        if self.deterministic:
+            return torch.Tensor([0.0])
+        return 0.5 * torch.sum(math.log(2.0 * math.pi) + self.logvar + torch.pow(sample - self.mean, 2) / self.var, dim=list(dims))
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+
 class AutoencoderKLCausal3D(nn.Module):
     def __init__(self, in_channels: int = 3, out_channels: int = 3, down_block_types=("DownEncoderBlockCausal3D",) * 4,
                  up_block_types=("UpDecoderBlockCausal3D",) * 4, block_out_channels=syn.VAE_BLOCK_OUT_CHANNELS,
                  layers_per_block: int = 2, act_fn: str = "silu", latent_channels: int = 16, norm_num_groups: int = 32,
                  sample_size: int = 256, sample_tsize: int = 64, scaling_factor: float = 0.476986,
                  force_upcast: bool = True, spatial_compression_ratio: int = 8, time_compression_ratio: int = 4,
-                 mid_block_add_attention: bool = True, device=None, dtype=F16):
+                 mid_block_add_attention: bool = True, device=None, dtype=F16, with_encoder: bool = False):
+        """with_encoder: also hold `encoder.*` / `quant_conv.*` (encode(), forward(): SURVEY.md 8f row 3).  Without it the
+        module is the decode half the denoise pipeline needs and checkpoint keys of the encode half are ignored on load."""
         super().__init__()
         if act_fn not in ("silu", "swish") or norm_num_groups != 32 or time_compression_ratio != 4 or \
                 spatial_compression_ratio != 8 or not mid_block_add_attention or len(block_out_channels) != 4:
@@ -62,8 +107,12 @@ class AutoencoderKLCausal3D(nn.Module):
                                       spatial_compression_ratio=spatial_compression_ratio,
                                       time_compression_ratio=time_compression_ratio, mid_block_add_attention=mid_block_add_attention)
         self.time_compression_ratio = time_compression_ratio
-        self._shapes = syn.vae_decoder_param_shapes(block_out_channels, latent_channels, out_channels, layers_per_block)
+        self._shapes = dict(syn.vae_decoder_param_shapes(block_out_channels, latent_channels, out_channels, layers_per_block))
+        self.with_encoder = with_encoder
+        if with_encoder:
+            self._shapes.update(syn.vae_encoder_param_shapes(block_out_channels, latent_channels, in_channels, layers_per_block))
         _build_tree(self, self._shapes, device, dtype)
+        self._t_ops = None
         self.use_slicing = False
         self.use_spatial_tiling = False
         self.use_temporal_tiling = False
@@ -111,7 +160,8 @@ class AutoencoderKLCausal3D(nn.Module):
         self.use_slicing = False
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        kept = {k: v for k, v in state_dict.items() if not (k.startswith("encoder.") or k.startswith("quant_conv."))}
+        kept = state_dict if self.with_encoder else \
+            {k: v for k, v in state_dict.items() if not (k.startswith("encoder.") or k.startswith("quant_conv."))}
         self._prep = None
         return super().load_state_dict(kept, strict=strict, assign=assign)
 
@@ -152,11 +202,12 @@ class AutoencoderKLCausal3D(nn.Module):
             elif k.endswith(".weight") and sd[k].dim() == 1:
                 name = k[:-len(".weight")]
                 P[name] = (sd[k].to(F16).contiguous(), sd[name + ".bias"].to(F16).contiguous())
-        a = "decoder.mid_block.attentions.0."
-        wqkv = torch.cat([sd[a + n + ".weight"] for n in ("to_q", "to_k", "to_v")], 0)
-        bqkv = torch.cat([sd[a + n + ".bias"] for n in ("to_q", "to_k", "to_v")], 0)
-        lin(a + "qkv", wqkv, bqkv)
-        lin(a + "to_out.0", sd[a + "to_out.0.weight"], sd[a + "to_out.0.bias"])
+        for half in (("decoder", "encoder") if self.with_encoder else ("decoder",)):
+            a = half + ".mid_block.attentions.0."
+            wqkv = torch.cat([sd[a + n + ".weight"] for n in ("to_q", "to_k", "to_v")], 0)
+            bqkv = torch.cat([sd[a + n + ".bias"] for n in ("to_q", "to_k", "to_v")], 0)
+            lin(a + "qkv", wqkv, bqkv)
+            lin(a + "to_out.0", sd[a + "to_out.0.weight"], sd[a + "to_out.0.bias"])
         self._prep = P
         return P
 
@@ -221,14 +272,26 @@ class AutoencoderKLCausal3D(nn.Module):
         V.gemm_f16(x, wpq, bpq, out=x1, n=wpq.shape[0], k=64)
         pre = "decoder."
         h = self._conv(P, pre + "conv_in.conv", x1, T, H, W)
-        h = self._resnet(P, pre + "mid_block.resnets.0.", h, T, H, W)
-        h = self._mid_attention(P, pre + "mid_block.attentions.0.", h, T, H * W)
-        h = self._resnet(P, pre + "mid_block.resnets.1.", h, T, H, W)
+        dec_ops = (self._t_ops or {}).get("decoder", {})
+        h, T = self._mid_block(P, pre + "mid_block.", h, T, H, W, dec_ops.get("mid_block"))
         boc = self.config.block_out_channels
         nb = len(boc)
+        n_res = self.config.layers_per_block + 1
         for i in range(nb):
-            for j in range(self.config.layers_per_block + 1):
+            bc = self._block_cfg(dec_ops.get("up_blocks"), i) or {}
+            eib = bc.get("enable_t_interp_before_block", [False] * n_res)
+            eia = bc.get("enable_t_interp_after_block", [False] * n_res)
+            if len(eib) != n_res or len(eia) != n_res:
+                raise ValueError(f"[UpDecoderBlockCausal3D] config mismatch: expecting {n_res} bools in each list.")
+            sc = int(bc.get("interp_t_scale_factor", 2))
+            if (any(eib) or any(eia)) and bc.get("interp_mode", "nearest") != "nearest":
+                raise NotImplementedError("t_ops interp_mode: only 'nearest' has a kernel (the fork's config default)")
+            for j in range(n_res):
+                if eib[j]:
+                    h, T = V.temporal_nearest_up(h, T, H * W, sc)      # unet_causal_3d_blocks.py:884-895
                 h = self._resnet(P, f"{pre}up_blocks.{i}.resnets.{j}.", h, T, H, W)
+                if eia[j]:
+                    h, T = V.temporal_nearest_up(h, T, H * W, sc)
             sp = i < 3
             tm = (i >= nb - 1 - 2) and (i != nb - 1)
             if sp or tm:
@@ -238,6 +301,202 @@ class AutoencoderKLCausal3D(nn.Module):
         h = self._gn(P, pre + "conv_norm_out", h)
         out = self._conv(P, pre + "conv_out.conv", h, T, H, W)
         return out, T, H, W
+
+    # ------------------------------------------------------------------ shared by both halves: mid block, t_ops bookkeeping
+    @staticmethod
+    def _block_cfg(cfgs, i):
+        for c in cfgs or []:
+            if c.get("block_index") == i:
+                return c
+        return None
+
+    @staticmethod
+    def _pool_conf(cfg, n_res, who):
+        """apply_t_ops_config / apply_t_ops_config_midblock (unet_causal_3d_blocks.py:622-645,736-762): per-resnet
+        (pool before, pool after, kernel, stride); kernel defaults to 2, stride to 2."""
+        if not cfg or "enable_t_pool_before_block" not in cfg:
+            return [(False, False, 0, 0)] * n_res
+        epb, epa = cfg.get("enable_t_pool_before_block", []), cfg.get("enable_t_pool_after_block", [])
+        if len(epb) != n_res or len(epa) != n_res:
+            raise ValueError(f"[{who}] T-ops config mismatch: we have {n_res} ResnetBlock(s), but got list lengths: "
+                             f"{[len(epb), len(epa)]}")
+        k, s = int(cfg.get("pool_t_kernel", 2)), int(cfg.get("pool_t_stride", 2))
+        return [(bool(epb[i]), bool(epa[i]), k, s) for i in range(n_res)]
+
+    def _mid_block(self, P, pre, h, T, H, W, cfg=None):
+        """UNetMidBlockCausal3D.forward (unet_causal_3d_blocks.py:647-674): resnet 0, attention, resnet 1, with the fork's
+        temporal pools around each resnet (the attention runs before resnet 1's `before` pool)."""
+        conf = self._pool_conf(cfg, 2, "UNetMidBlockCausal3D")
+        for i in range(2):
+            if i > 0:
+                h = self._mid_attention(P, pre + "attentions.0.", h, T, H * W)
+            before, after, k, s = conf[i]
+            if before:
+                h, T = V.temporal_avg_pool(h, T, H * W, k, s)
+            h = self._resnet(P, f"{pre}resnets.{i}.", h, T, H, W)
+            if after:
+                h, T = V.temporal_avg_pool(h, T, H * W, k, s)
+        return h, T
+
+    def apply_t_ops_config(self, t_ops_config):
+        """The fork's `_apply_t_ops_config_to_vae(vae, cfg)` (vae/__init__.py:15-63): `t_ops_config` is the parsed
+        t_ops_config.json (or None to clear).  Validated here so a malformed config fails at load time, like the reference."""
+        if t_ops_config is not None:
+            n = self.config.layers_per_block
+            enc, dec = t_ops_config.get("encoder", {}), t_ops_config.get("decoder", {})
+            for bc in enc.get("down_blocks", []):
+                self._pool_conf(bc, n, "DownEncoderBlockCausal3D")
+            self._pool_conf(enc.get("mid_block"), 2, "UNetMidBlockCausal3D")
+            self._pool_conf(dec.get("mid_block"), 2, "UNetMidBlockCausal3D")
+            for bc in dec.get("up_blocks", []):
+                for key in ("enable_t_interp_before_block", "enable_t_interp_after_block"):
+                    if len(bc.get(key, [False] * (n + 1))) != n + 1:
+                        raise ValueError(f"[UpDecoderBlockCausal3D] config mismatch: expecting {n + 1} bools in each list.")
+        self._t_ops = t_ops_config
+        return self
+
+    # ------------------------------------------------------------------ encoder on one video tile (SURVEY.md 8f row 3)
+    def _encode_tile(self, x_view: torch.Tensor) -> Tuple[torch.Tensor, int, int, int]:
+        """x_view: [3,T,H,W] strided view (any float dtype) -> (moments, channels-last fp16 [T'*H'*W', 2*latent], T', H', W').
+        EncoderCausal3D.forward + quant_conv (vae/vae.py:116-136, autoencoder_kl_causal_3d.py:289-292)."""
+        if not self.with_encoder:
+            raise RuntimeError("this AutoencoderKLCausal3D was built without the encode half (with_encoder=False)")
+        P = self._prepare()
+        c, T, H, W = x_view.shape
+        x = V.latent_tile(x_view if x_view.dtype == torch.float32 else x_view.to(torch.float32), 64)
+        pre = "encoder."
+        enc_ops = (self._t_ops or {}).get("encoder", {})
+        h = self._conv(P, pre + "conv_in.conv", x, T, H, W)
+        boc = self.config.block_out_channels
+        nb, n_res = len(boc), self.config.layers_per_block
+        for i in range(nb):
+            bc = self._block_cfg(enc_ops.get("down_blocks"), i)
+            conf = self._pool_conf(bc, n_res, "DownEncoderBlockCausal3D")
+            for j in range(n_res):
+                before, after, k, s = conf[j]
+                if before:
+                    h, T = V.temporal_avg_pool(h, T, H * W, k, s)      # unet_causal_3d_blocks.py:764-770
+                h = self._resnet(P, f"{pre}down_blocks.{i}.resnets.{j}.", h, T, H, W)
+                if after:
+                    h, T = V.temporal_avg_pool(h, T, H * W, k, s)
+            sp = i < 3
+            tm = (i >= nb - 1 - 2) and (i != nb - 1)
+            if sp or tm:
+                stride = ((2 if tm else 1), (2 if sp else 1), (2 if sp else 1))
+                if bc and "downsample_stride" in bc:
+                    stride = tuple(int(v) for v in bc["downsample_stride"])      # :737-742
+                wt, b, cip, cop = P[f"{pre}down_blocks.{i}.downsamplers.0.conv.conv"]
+                h, T, H, W = V.conv3d_causal_strided(self._pad_channels(h, cip), wt, b, T, H, W, cip, cop, stride)
+        h, T = self._mid_block(P, pre + "mid_block.", h, T, H, W, enc_ops.get("mid_block"))
+        h = self._gn(P, pre + "conv_norm_out", h)
+        h = self._conv(P, pre + "conv_out.conv", h, T, H, W)
+        wq, bq = P["quant_conv"]
+        moments = V.gemm_f16(self._pad_channels(h, wq.shape[1]), wq, bq, k=wq.shape[1])
+        return moments, T, H, W
+
+    def _plain_encode(self, x4):
+        buf, T, H, W = self._encode_tile(x4)
+        c = 2 * self.config.latent_channels
+        out = torch.empty(c, T, H, W, dtype=F16, device=buf.device)
+        V.copy4d_(self._cl_view(buf, T, H, W, c), out)
+        return out
+
+    def _spatial_tiled_encode(self, x4):
+        """autoencoder_kl_causal_3d.py:362-420 on a [3,T,H,W] view; returns planar fp16 moments [2*latent,T',H',W']."""
+        ov = int(self.tile_sample_min_size * (1 - self.tile_overlap_factor))
+        ext = int(self.tile_latent_min_size * self.tile_overlap_factor)
+        lim = self.tile_latent_min_size - ext
+        c = 2 * self.config.latent_channels
+        rows = []
+        for i in range(0, x4.shape[-2], ov):
+            row = []
+            for j in range(0, x4.shape[-1], ov):
+                buf, T, H, W = self._encode_tile(x4[:, :, i:i + self.tile_sample_min_size, j:j + self.tile_sample_min_size])
+                row.append(self._cl_view(buf, T, H, W, c))
+            rows.append(row)
+        heights = [min(r[0].shape[2], lim) for r in rows]
+        widths = [min(t.shape[3], lim) for t in rows[0]]
+        out = torch.empty(c, rows[0][0].shape[1], sum(heights), sum(widths), dtype=F16, device=x4.device)
+        y0 = 0
+        for i, row in enumerate(rows):
+            x0 = 0
+            for j, tile in enumerate(row):
+                if i > 0:
+                    a = rows[i - 1][j]
+                    e = min(a.shape[2], tile.shape[2], ext)
+                    V.blend_(a[:, :, a.shape[2] - e:, :], tile[:, :, :e, :], 2, e)
+                if j > 0:
+                    a = row[j - 1]
+                    e = min(a.shape[3], tile.shape[3], ext)
+                    V.blend_(a[:, :, :, a.shape[3] - e:], tile[:, :, :, :e], 3, e)
+                V.copy4d_(tile[:, :, :heights[i], :widths[j]], out[:, :, y0:y0 + heights[i], x0:x0 + widths[j]])
+                x0 += widths[j]
+            y0 += heights[i]
+        return out
+
+    def _temporal_tiled_encode(self, x4):
+        """autoencoder_kl_causal_3d.py:470-510."""
+        T = x4.shape[1]
+        ov = int(self.tile_sample_min_tsize * (1 - self.tile_overlap_factor))
+        ext = int(self.tile_latent_min_tsize * self.tile_overlap_factor)
+        lim = self.tile_latent_min_tsize - ext
+        row = []
+        for i in range(0, T, ov):
+            tile = x4[:, i:i + self.tile_sample_min_tsize + 1]
+            if self.use_spatial_tiling and (tile.shape[-1] > self.tile_sample_min_size or tile.shape[-2] > self.tile_sample_min_size):
+                enc = self._spatial_tiled_encode(tile)
+            else:
+                enc = self._plain_encode(tile)
+            if i > 0:
+                enc = enc[:, 1:]
+            row.append(enc)
+        lens = [min(t.shape[1], lim + (1 if i == 0 else 0)) for i, t in enumerate(row)]
+        out = torch.empty(row[0].shape[0], sum(lens), row[0].shape[2], row[0].shape[3], dtype=F16, device=x4.device)
+        t0 = 0
+        for i, tile in enumerate(row):
+            if i > 0:
+                a = row[i - 1]
+                e = min(a.shape[1], tile.shape[1], ext)
+                if e > 0:
+                    V.blend_(a[:, a.shape[1] - e:], tile[:, :e], 1, e)
+            if lens[i] > 0:
+                V.copy4d_(tile[:, :lens[i]], out[:, t0:t0 + lens[i]])
+            t0 += lens[i]
+        return out
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """autoencoder_kl_causal_3d.py:259-296: x [B,3,T,H,W] -> AutoencoderKLOutput(latent_dist) / (posterior,)."""
+        assert len(x.shape) == 5, "The input tensor should have 5 dimensions."
+        if x.shape[0] != 1:
+            moments = torch.cat([self._encode_moments(xs) for xs in x.split(1)])
+        else:
+            moments = self._encode_moments(x)
+        posterior = DiagonalGaussianDistribution(moments)
+        if not return_dict:
+            return (posterior,)
+        return SimpleNamespace(latent_dist=posterior, tiles_ci=None)
+
+    def _encode_moments(self, x):
+        x4 = x[0]
+        if self._t_ops is not None and (self.use_temporal_tiling or self.use_spatial_tiling):
+            raise NotImplementedError("t_ops change the compression ratios the tile/blend geometry assumes; the fork runs them untiled")
+        if self.use_temporal_tiling and x4.shape[1] > self.tile_sample_min_tsize:
+            return self._temporal_tiled_encode(x4)[None]
+        if self.use_spatial_tiling and (x4.shape[-1] > self.tile_sample_min_size or x4.shape[-2] > self.tile_sample_min_size):
+            return self._spatial_tiled_encode(x4)[None]
+        return self._plain_encode(x4)[None]
+
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, sample_posterior: bool = False, return_dict: bool = True,
+                return_posterior: bool = False, generator: Optional[torch.Generator] = None):
+        """autoencoder_kl_causal_3d.py:545-580 (what the fork's infer.py:52-57 calls): encode -> sample()/mode() -> decode."""
+        posterior = self.encode(sample).latent_dist
+        z = posterior.sample(generator=generator) if sample_posterior else posterior.mode()
+        dec = self.decode(z).sample
+        if not return_dict:
+            return (dec, posterior) if return_posterior else (dec,)
+        return SimpleNamespace(sample=dec, posterior=posterior) if return_posterior else SimpleNamespace(sample=dec)
 
     # ------------------------------------------------------------------ tiling (reference loop order)
     @staticmethod
@@ -399,6 +658,8 @@ class AutoencoderKLCausal3D(nn.Module):
             raise NotImplementedError("batch 1 (use_slicing splits larger batches)")
         z4 = z[0].to(torch.float32)
         self._tile_queue = None
+        if self._t_ops is not None and (self.use_temporal_tiling or self.use_spatial_tiling):
+            raise NotImplementedError("t_ops change the compression ratios the tile/blend geometry assumes; the fork runs them untiled")
         if getattr(self, "_tp_enabled", False):
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(self._tp_group) > 1:

@@ -104,7 +104,8 @@ def test_vae_checkpoint_wrappers_and_config(tmp_path):
     from hunyuanvideo_efficiency_amd.vae import load_vae
     boc = (32, 64, 128, 128)
     sd = {k: v.to(torch.float16) for k, v in syn.synth_vae_state_dict(boc, seed=2).items()}
-    extra = {"encoder.conv_in.conv.weight": torch.zeros(4, 3, 3, 3, 3), "quant_conv.weight": torch.zeros(2, 2, 1, 1, 1)}
+    # a real checkpoint carries the encode half too: load_vae then builds it (with_encoder=None -> detected from the keys)
+    extra = {k: v.to(torch.float16) for k, v in syn.synth_vae_state_dict(boc, seed=2, encoder=True).items() if k not in sd}
     for wrap in (lambda s: s, lambda s: {"state_dict": s}, lambda s: {"state_dict": {"vae." + k: v for k, v in s.items()}}):
         d = tmp_path / f"vae{id(wrap)}"
         d.mkdir()
@@ -115,7 +116,10 @@ def test_vae_checkpoint_wrappers_and_config(tmp_path):
         assert (sr, tr) == (8, 4) and vae.config.scaling_factor == 0.5 and vae.config.block_out_channels == boc
         assert (vae.tile_latent_min_size, vae.tile_latent_min_tsize) == (16, 4)
         got = vae.state_dict()
-        assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+        assert vae.with_encoder and set(got) == set(sd) | set(extra) and all(torch.equal(got[k], {**sd, **extra}[k]) for k in got)
+        # decode-only build of the same checkpoint: the encode half's keys are ignored
+        vae2 = load_vae("884-16c-hy", "fp16", vae_path=str(d), device="cpu", with_encoder=False)[0]
+        assert set(vae2.state_dict()) == set(sd)
     with pytest.raises(ValueError):
         ck.read_vae_checkpoint(tmp_path / "nowhere")
 
