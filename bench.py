@@ -27,6 +27,7 @@ WORKLOADS = {
     # name: (latent T, H, W)
     "720p129f": (33, 90, 160),
     "544p65f": (17, 68, 120),
+    "720p257f": (65, 90, 160),
     "tiny": (5, 16, 16),
 }
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
@@ -85,6 +86,8 @@ def main():
                     "(pack/unpack + self all-to-all + chunked QKV GEMMs) to price its overhead")
     ap.add_argument("--ring-degree", type=int, default=1, help="N > 1: hybrid Ulysses x Ring with this ring degree (ulysses = N / ring); "
                     "default 1 = pure Ulysses")
+    ap.add_argument("--use-fp8", action="store_true", help="BASELINE.json configs[3]: FP8 (e4m3) weight storage for the block linears, "
+                    "dequantised per call into the bf16 MFMA GEMM (the reference's weight-only semantics)")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-by-`value`) VAE tiled decode of the same video")
     a = ap.parse_args()
 
@@ -113,6 +116,9 @@ def main():
     T, H, W = WORKLOADS[a.workload]
     s_img, s_txt = T * (H // 2) * (W // 2), 256
     model = build_model(cfg, dev, seed=0)
+    if a.use_fp8:
+        from hunyuanvideo_efficiency_amd.modules.fp8_optimization import convert_fp8_linear
+        convert_fp8_linear(model, None, torch.bfloat16)
     if world > 1 or a.force_sp:
         from hunyuanvideo_efficiency_amd.inference import parallelize_transformer_module
         if a.ring_degree > 1:
@@ -201,7 +207,8 @@ def main():
             traffic_note = ("bytes/launch from profiles/r01/attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes); "
                             f"algorithmic {tj['algorithmic_bytes_per_launch']:.3e} B; counter includes Infinity-Cache hits (per-XCD K/V re-streams)")
         out = {
-            "metric": "denoise-steps/sec (720x1280x129f, HunyuanVideo DiT 20+40 blocks, bf16)" if not tiny else "denoise-steps/sec (tiny)",
+            "metric": ("denoise-steps/sec (" + {"720p129f": "720x1280x129f", "544p65f": "544x960x65f", "720p257f": "720x1280x257f"}.get(a.workload, a.workload)
+                       + ", HunyuanVideo DiT 20+40 blocks, " + ("bf16 compute, fp8 e4m3 weights)" if a.use_fp8 else "bf16)")) if not tiny else "denoise-steps/sec (tiny)",
             "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (hash-generated latents/text embeddings, random-init weights)",
