@@ -94,31 +94,40 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v2(AttnArgs a) {
     }
 
     // ---- DMA addressing: wave w owns keys [8w, 8w+8) of a tile; piece i (0,1): key = 8w + 4i + (lane>>4), LDS chunk pos = lane&15
+    // Source address = wave-uniform tile base (scalar registers, advanced by scalar adds) + a per-lane byte offset that never
+    // changes: no vector integer work per tile.  Only a partial last tile takes the slow path that clamps rows to n_kv - 1.
     const int dkey0 = 8 * wave + (lane >> 4), dcp = lane & 15;
-    const bf16_t* kcol[2];
-    const bf16_t* vcol[2];
+    const char* kbase = reinterpret_cast<const char*>(a.k + head * D);
+    const char* vbase = reinterpret_cast<const char*>(a.v + head * D);
+    uint32_t koff[2], voff[2], koff_last[2], voff_last[2];
+    const int last_tile = (a.n_kv + KVT - 1) / KVT - 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int key = dkey0 + 4 * i;
-        kcol[i] = a.k + head * D + ((dcp ^ (key & 15)) << 3);
-        vcol[i] = a.v + head * D + ((dcp ^ ((key & 3) << 2)) << 3);
+        const int kx = ((dcp ^ (key & 15)) << 4), vx = ((dcp ^ ((key & 3) << 2)) << 4);
+        koff[i] = (uint32_t)(key * (int)a.sk * 2 + kx);
+        voff[i] = (uint32_t)(key * (int)a.sv * 2 + vx);
+        const int keyl = min(key, a.n_kv - 1 - last_tile * KVT);      // rows past the end re-read the last valid row
+        koff_last[i] = (uint32_t)(keyl * (int)a.sk * 2 + kx);
+        voff_last[i] = (uint32_t)(keyl * (int)a.sv * 2 + vx);
     }
-    const int wave_lds = wave * 2048;   // 8 keys x 256 B
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 2048;   // 8 keys x 256 B; scalar: the DMA destination goes through M0
+    const int64_t k_tile_bytes = (int64_t)KVT * a.sk * 2, v_tile_bytes = (int64_t)KVT * a.sv * 2;
     auto dma_k = [&](int tile, int buf) {
+        const char* tb = kbase + tile * k_tile_bytes;
+        const bool lastt = tile == last_tile;      // wave-uniform select, no branch
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = min(tile * KVT + dkey0 + 4 * i, a.n_kv - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(kcol[i] + (int64_t)key * a.sk),
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(tb + (lastt ? koff_last[i] : koff[i])),
                                              (lds_void_ptr)(smem + KOFF + buf * KV_TILE_BYTES + wave_lds + i * 1024), 16, 0, 0);
-        }
     };
     auto dma_v = [&](int tile, int buf) {
+        const char* tb = vbase + tile * v_tile_bytes;
+        const bool lastt = tile == last_tile;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = min(tile * KVT + dkey0 + 4 * i, a.n_kv - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(vcol[i] + (int64_t)key * a.sv),
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(tb + (lastt ? voff_last[i] : voff[i])),
                                              (lds_void_ptr)(smem + VOFF + buf * KV_TILE_BYTES + wave_lds + i * 1024), 16, 0, 0);
-        }
     };
 
     int kread[2];

@@ -1,30 +1,15 @@
-import sys, math, torch
+import sys, torch
 sys.path.insert(0, '.')
 from hunyuanvideo_efficiency_amd import ops
 torch.manual_seed(0)
-dev='cuda'
-def run(q,k,v):
-    n_q=q.shape[0]; out=torch.empty(n_q,128,dtype=torch.bfloat16,device=dev)
-    ops.attn_fwd(q.to(dev),k.to(dev),v.to(dev),out,1); torch.cuda.synchronize(); return out.float().cpu()
-def ref(q,k,v):
-    s=(q.float()@k.float().T)/math.sqrt(128); p=s.softmax(-1); return p@v.float()
-bf=torch.bfloat16
-n=64
-# A: q=0 -> mean of V; V[key][d] = d
-q=torch.zeros(n,128,dtype=bf); k=torch.randn(n,128).to(bf); v=torch.arange(128.)[None].expand(n,128).contiguous().to(bf)
-o=run(q,k,v); print("A (expect 0..127):", o[0,:8].tolist(), o[0,120:].tolist(), "maxerr", (o-ref(q,k,v)).abs().max().item())
-# B: q=0, V[key][d]=key -> 31.5
-v=torch.arange(float(n))[:,None].expand(n,128).contiguous().to(bf)
-o=run(q,k,v); print("B (expect 31.5):", o[0,:4].tolist(), o[40,:4].tolist())
-# C: one-hot attention: k[j]=e_j*big, q[i]=e_{pi(i)}*big -> out[i]=v[pi(i)]
-big=30.0
-k=torch.zeros(n,128); k[torch.arange(n),torch.arange(n)]=big
-perm=(torch.arange(n)*7+3)%n
-q=torch.zeros(n,128); q[torch.arange(n),perm]=big
-v=torch.arange(float(n))[:,None].expand(n,128).contiguous()
-o=run(q.to(bf),k.to(bf),v.to(bf)); print("C expect", perm[:16].tolist()); print("C got   ", o[:16,0].tolist()); print("C got d5", o[:16,5].tolist())
-# D: one-hot with v[key][d]=d + 1000*key?? keep small: v[key][d]= (key*128+d)%251
-v=((torch.arange(n)[:,None]*128+torch.arange(128)[None])%251).float()
-o=run(q.to(bf),k.to(bf),v.to(bf)); r=ref(q.to(bf),k.to(bf),v.to(bf)); print("D maxerr", (o-r).abs().max().item()); 
-bad=(o-r).abs()>1
-print("D bad rows", bad.any(1).nonzero().flatten().tolist()[:20], "bad cols", bad.any(0).nonzero().flatten().tolist()[:40])
+for (nq, nkv, H) in ((64, 64, 1), (64, 128, 1), (256, 64, 1), (300, 200, 2)):
+    q = torch.randn(nq, H*128, device='cuda').to(torch.bfloat16); k = torch.randn(nkv, H*128, device='cuda').to(torch.bfloat16); v = torch.randn(nkv, H*128, device='cuda').to(torch.bfloat16)
+    o = torch.empty_like(q)
+    ops.attn_fwd(q, k, v, o, H)
+    qf, kf, vf = (t.float().view(t.shape[0], H, 128).transpose(0, 1) for t in (q, k, v))
+    ref = torch.softmax(qf @ kf.transpose(1, 2) / 128 ** 0.5, -1) @ vf
+    ref = ref.transpose(0, 1).reshape(nq, H*128)
+    ratio = (o.float() / ref)
+    err = (o.float() - ref).abs().max().item()
+    rr = ratio[:, :8].median(dim=1).values
+    print(nq, nkv, H, "max err", err, "row ratio (first 8 rows)", rr[:8].tolist(), "rows 32..36", rr[32:36].tolist())
