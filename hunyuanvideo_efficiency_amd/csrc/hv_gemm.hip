@@ -129,7 +129,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         const int wr = min(n0 + row, g.N - 1);
         w_src[i] = g.W + (int64_t)wr * g.ldw + ((scp ^ swz_w(row)) << 3);
     }
-    const int wave_lds = wave * 1024;  // wave-uniform base of this wave's 1 KiB slice of each piece
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;  // this wave's 1 KiB slice of each piece; scalar: the DMA
+                                                                        // destination goes through M0, no VALU/readfirstlane per piece
+    // Plain GEMM: source = scalar tile base (advanced by scalar adds per K-tile) + invariant per-lane byte offset -> the saddr form
+    // of global_load_lds, no 64-bit vector address arithmetic in the K loop.  (Conv mode gathers a different row per tap.)
+    const char* a_tile = reinterpret_cast<const char*>(g.A + (int64_t)m0 * g.lda);
+    const char* w_tile = reinterpret_cast<const char*>(g.W + (int64_t)n0 * g.ldw);
+    uint32_t a_o[4], w_o[WPIECES];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 64 + srow;
+        a_o[i] = (uint32_t)(((int64_t)(min(m0 + row, g.M - 1) - m0) * g.lda + ((scp ^ swz_a(row)) << 3)) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < WPIECES; ++i) {
+        const int row = i * 64 + srow;
+        w_o[i] = (uint32_t)(((int64_t)(min(n0 + row, g.N - 1) - n0) * g.ldw + ((scp ^ swz_w(row)) << 3)) * 2);
+    }
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE_BYTES + wave_lds;
@@ -149,13 +165,25 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + srcrow * g.lda + c0), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
             }
         } else {
+            uint64_t abv = reinterpret_cast<uint64_t>(a_tile + koff * 2);
+            asm volatile("" : "+s"(abv));      // keep the tile base a scalar pair: stops the compiler folding it into per-lane 64-bit pointers
+            const char* ab = reinterpret_cast<const char*>(abv);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + koff), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                uint32_t o = a_o[i];
+                asm volatile("" : "+v"(o));    // opaque per iteration: the zero-extension stays next to the load (saddr + 32-bit voffset form)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ab + o), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
+            }
         }
+        uint64_t wbv = reinterpret_cast<uint64_t>(w_tile + koff * 2);
+        asm volatile("" : "+s"(wbv));
+        const char* wb = reinterpret_cast<const char*>(wbv);
 #pragma unroll
-        for (int i = 0; i < WPIECES; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + koff), (lds_ptr_t)(base + TILE_BYTES + i * 8192), 16, 0, 0);
+        for (int i = 0; i < WPIECES; ++i) {
+            uint32_t o = w_o[i];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wb + o), (lds_ptr_t)(base + TILE_BYTES + i * 8192), 16, 0, 0);
+        }
     };
 
     // ---- fragment read offsets (bytes inside an operand tile), k-step 0; k-step 1 flips chunk bit 2
