@@ -38,6 +38,16 @@ def parse_args():
     p.add_argument("--model-base", default=None, help="root holding t2v_<resolution>/ when --dit-weight is a bare name")
     p.add_argument("--model-resolution", default="540p")
     p.add_argument("--vae-path", default=None, help="directory with the reference's VAE config.json + pytorch_model.pt")
+    p.add_argument("--prompt", default=None, help="text prompt; needs --text-encoder-path (+ --text-encoder-2-path). Default: synthetic "
+                                                   "prompt embeddings (no text-encoder checkpoints exist in this environment)")
+    p.add_argument("--text-encoder-path", default=None, help="HF directory of the LLM text encoder (+ tokenizer)")
+    p.add_argument("--text-encoder-2-path", default=None, help="HF directory of CLIP-L (+ tokenizer)")
+    p.add_argument("--text-encoder-precision", default="fp16")
+    p.add_argument("--text-len-2", type=int, default=77)
+    p.add_argument("--prompt-template", default="dit-llm-encode")
+    p.add_argument("--prompt-template-video", default="dit-llm-encode-video")
+    p.add_argument("--hidden-state-skip-layer", type=int, default=2)
+    p.add_argument("--apply-final-norm", action="store_true")
     p.add_argument("--tiny", action="store_true", help="tiny DiT (d=256, 1+1 blocks) and reduced VAE: plumbing check")
     p.add_argument("--save-path", default="./results")
     return p.parse_args()
@@ -77,7 +87,21 @@ def main():
             for k, p in vae.state_dict().items():
                 p.copy_(syn.synth_param("vae." + k, tuple(p.shape), 0, dev).to(p.dtype))
     sched = FlowMatchDiscreteScheduler(shift=a.flow_shift, reverse=a.flow_reverse, solver=a.flow_solver)
-    pipe = HunyuanVideoPipeline(vae, model, sched, a)
+    text_encoder = text_encoder_2 = None
+    if a.prompt is not None:
+        # inference.py:216-265: max_length = text_len + crop_start of the video template
+        if a.text_encoder_path is None:
+            raise ValueError("--prompt needs --text-encoder-path (a Hugging Face model directory)")
+        from hunyuanvideo_efficiency_amd.constants import PROMPT_TEMPLATE
+        from hunyuanvideo_efficiency_amd.text_encoder import TextEncoder
+        tv = PROMPT_TEMPLATE[a.prompt_template_video]
+        text_encoder = TextEncoder("llm", a.text_len + tv.get("crop_start", 0), a.text_encoder_precision, a.text_encoder_path,
+                                   tokenizer_type="llm", prompt_template=PROMPT_TEMPLATE[a.prompt_template], prompt_template_video=tv,
+                                   hidden_state_skip_layer=a.hidden_state_skip_layer, apply_final_norm=a.apply_final_norm, device=dev)
+        if a.text_encoder_2_path is not None:
+            text_encoder_2 = TextEncoder("clipL", a.text_len_2, a.text_encoder_precision, a.text_encoder_2_path, tokenizer_type="clipL",
+                                         device=dev)
+    pipe = HunyuanVideoPipeline(vae, model, sched, a, text_encoder=text_encoder, text_encoder_2=text_encoder_2)
     if a.ulysses_degree > 1:
         parallelize_transformer(pipe)
     lt = (a.video_length - 1) // 4 + 1
@@ -86,15 +110,22 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(a.seed)
     torch.cuda.synchronize()
     t0 = time.time()
-    out = pipe(ts.to(torch.float16), tm, ts2.to(torch.float16), h, w, a.video_length, num_inference_steps=a.infer_steps,
-               guidance_scale=a.cfg_scale, embedded_guidance_scale=a.embedded_cfg_scale, generator=gen, freqs_cis=freqs,
-               vae_ver=a.vae, enable_tiling=a.vae_tiling, n_tokens=freqs[0].shape[0])
+    common = dict(height=h, width=w, video_length=a.video_length, num_inference_steps=a.infer_steps, guidance_scale=a.cfg_scale,
+                  embedded_guidance_scale=a.embedded_cfg_scale, generator=gen, freqs_cis=freqs, vae_ver=a.vae,
+                  enable_tiling=a.vae_tiling, n_tokens=freqs[0].shape[0])
+    if a.prompt is not None:
+        out = pipe(prompt=a.prompt, prompt_embeds_2=None if text_encoder_2 is not None else ts2.to(torch.float16), data_type="video",
+                   **common)
+    else:
+        out = pipe(ts.to(torch.float16), tm, ts2.to(torch.float16), **common)
     dt = time.time() - t0
     if rank == 0:
         v = out.videos
         print(f"Success, time: {dt:.2f} s; video tensor {tuple(v.shape)} {v.dtype} range [{float(v.min()):.3f}, {float(v.max()):.3f}]")
         os.makedirs(a.save_path, exist_ok=True)
         torch.save(v[:, :, :1].clone(), os.path.join(a.save_path, "first_frame.pt"))
+        from hunyuanvideo_efficiency_amd.utils.file_utils import save_videos_grid
+        print("Sample save to:", save_videos_grid(v, os.path.join(a.save_path, f"seed{a.seed}.mp4"), fps=24))
 
 
 if __name__ == "__main__":

@@ -78,3 +78,45 @@ def test_pipeline_denoise_and_decode_vs_oracle():
     img = vae_ops.postprocess(y.contiguous()).cpu().float()
     assert float((img - ref).abs().max()) < 2e-2
     assert float((img - ref).abs().mean()) < 1e-3
+
+
+def test_pipeline_prompt_surface_with_text_encoders():
+    """`pipe(prompt=...)` (the reference's keyword surface): tiny random LLM + CLIP text encoders on the GPU feed the DiT; the result
+    must equal the run that is handed the same embeddings explicitly."""
+    from tests.test_text_encoder_cpu import _llm, _toy_tokenizer
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from hunyuanvideo_efficiency_amd.text_encoder import TextEncoder
+    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.vae import AutoencoderKLCausal3D
+    from hunyuanvideo_efficiency_amd.diffusion.schedulers import FlowMatchDiscreteScheduler
+    from hunyuanvideo_efficiency_amd.diffusion.pipelines import HunyuanVideoPipeline
+    from hunyuanvideo_efficiency_amd.inference import get_rotary_pos_embed
+    cfg = syn.DiTConfig(hidden_size=256, heads_num=2, mm_double_blocks_depth=1, mm_single_blocks_depth=1, text_states_dim=64,
+                        text_states_dim_2=64)      # the GEMM contracts over multiples of 64 (real model: 4096 / 768)
+    model = build_model(cfg, DEV, seed=0)
+    boc = (32, 64, 128, 128)
+    vae = AutoencoderKLCausal3D(block_out_channels=boc, device=DEV)
+    vae.load_state_dict({k: v.to(torch.float16) for k, v in syn.synth_vae_state_dict(boc, seed=0).items()}, strict=True)
+    tpl = {"template": "describe the video : {}", "crop_start": 4}
+    te = TextEncoder("llm", max_length=16 + 4, text_encoder_precision="fp16", prompt_template=tpl, prompt_template_video=tpl,
+                     hidden_state_skip_layer=2, model=_llm(64), tokenizer=_toy_tokenizer(64), device=DEV)
+    torch.manual_seed(1)
+    clip = CLIPTextModel(CLIPTextConfig(vocab_size=32, hidden_size=64, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4,
+                                        max_position_embeddings=16, projection_dim=64, pad_token_id=0, bos_token_id=1, eos_token_id=2))
+    te2 = TextEncoder("clipL", max_length=10, text_encoder_precision="fp16", model=clip, tokenizer=_toy_tokenizer(16), device=DEV)
+    pipe = HunyuanVideoPipeline(vae, model, FlowMatchDiscreteScheduler(shift=7.0, reverse=True, solver="euler"), types.SimpleNamespace(),
+                                text_encoder=te, text_encoder_2=te2)
+    frames, height, width = 5, 64, 64
+    freqs = get_rotary_pos_embed(model, frames, height, width, "884-16c-hy", 256, device=DEV)
+    x0 = syn.hashed_uniform((1, 16, 2, 8, 8), "prompt.lat", 2) * 1.7
+    kw = dict(height=height, width=width, video_length=frames, num_inference_steps=2, embedded_guidance_scale=6.0, freqs_cis=freqs,
+              enable_tiling=False, n_tokens=freqs[0].shape[0])
+    prompt = "a cat walks on grass [EOS]"
+    v1 = pipe(prompt=prompt, data_type="video", latents=x0.clone(), **kw).videos
+    emb, _, mask, _ = pipe.encode_prompt(prompt, DEV, data_type="video")
+    emb2 = pipe.encode_prompt(prompt, DEV, text_encoder=te2, data_type="video")[0]
+    assert emb.shape == (1, 16, 64) and emb.dtype == torch.float16 and int(mask.sum()) == 6 and emb2.shape == (1, 64)
+    v2 = pipe(emb, mask, emb2, latents=x0.clone(), **kw).videos
+    assert v1.shape == (1, 3, frames, height, width) and torch.equal(v1, v2)
+    with pytest.raises(ValueError):
+        HunyuanVideoPipeline(vae, model, pipe.scheduler)(prompt="x", **kw)
