@@ -108,17 +108,34 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     const int srow = tid >> 3, scp = tid & 7;  // row within a 64-row piece, 16-B chunk position in LDS
     const uint16_t* a_src[4];
     const uint16_t* w_src[WPIECES];
-    int vt[4], vh[4], vw[4];   // conv: output voxel of each staged row
+    // conv: the source row of tap (dt,dh,dw) separates into a frame, a line and a column term.  All nine terms of each staged row
+    // are formed ONCE here as byte offsets (replicate/causal padding = the clamps, nearest upsample = the halvings, stride = the
+    // coordinate multipliers); the K loop only selects three of them with wave-uniform conditions and adds: no multiplies, clamps or
+    // 64-bit arithmetic per K-tile (that arithmetic used to cost about as many issue cycles as the tile's MFMAs at BN = 128).
+    uint32_t offT[4][3], offH[4][3], offW[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = i * 64 + srow;
         const int ar = min(m0 + row, g.M - 1);  // clamp: tails read valid rows
         if (CONV) {
-            vw[i] = (ar % g.cW) * g.mw;
+            const int vw = (ar % g.cW) * g.mw;
             const int th = ar / g.cW;
-            vh[i] = (th % g.cH) * g.mh;
-            vt[i] = (th / g.cH) * g.mt;
-            a_src[i] = g.A + ((scp ^ swz_a(row)) << 3);
+            const int vh = (th % g.cH) * g.mh;
+            const int vt = (th / g.cH) * g.mt;
+            const uint32_t row_bytes = (uint32_t)g.lda * 2u;
+            uint32_t aT[3], aH[3], aW[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                int ti = max(vt + d - 2, 0);
+                if (g.up_t) ti = ti == 0 ? 0 : 1 + ((ti - 1) >> 1);
+                aT[d] = (uint32_t)ti * (uint32_t)(g.sH * g.sW) * row_bytes;
+                aH[d] = (uint32_t)(min(max(vh + d - 1, 0), g.bH - 1) >> g.up_hw) * (uint32_t)g.sW * row_bytes;
+                aW[d] = (uint32_t)(min(max(vw + d - 1, 0), g.bW - 1) >> g.up_hw) * row_bytes + (uint32_t)((scp ^ swz_a(row)) << 4);
+            }
+            offT[i][0] = aT[0]; offT[i][1] = aT[1] - aT[0]; offT[i][2] = aT[2] - aT[1];
+            offH[i][0] = aH[0]; offH[i][1] = aH[1] - aH[0]; offH[i][2] = aH[2] - aH[1];
+            offW[i][0] = aW[0]; offW[i][1] = aW[1] - aW[0]; offW[i][2] = aW[2] - aW[1];
+            a_src[i] = g.A;
         } else {
             a_src[i] = g.A + (int64_t)ar * g.lda + ((scp ^ swz_a(row)) << 3);
         }
@@ -153,16 +170,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         if (CONV) {
             const int tap = koff / g.cin, c0 = koff - tap * g.cin;
             const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+            uint64_t abv = reinterpret_cast<uint64_t>(g.A + c0);
+            asm volatile("" : "+s"(abv));
+            const char* ab = reinterpret_cast<const char*>(abv);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int ti = max(vt[i] + dt - 2, 0);
-                int hi = min(max(vh[i] + dh - 1, 0), g.bH - 1);
-                int wi = min(max(vw[i] + dw - 1, 0), g.bW - 1);
-                if (g.up_t) ti = ti == 0 ? 0 : 1 + ((ti - 1) >> 1);
-                hi >>= g.up_hw;
-                wi >>= g.up_hw;
-                const int64_t srcrow = ((int64_t)ti * g.sH + hi) * g.sW + wi;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + srcrow * g.lda + c0), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
+                // [0] = term of tap coordinate 0, [1] / [2] = increments to coordinates 1 / 2 (so a select is "add or add nothing")
+                uint32_t o = offT[i][0] + (dt >= 1 ? offT[i][1] : 0u) + (dt >= 2 ? offT[i][2] : 0u) +
+                             offH[i][0] + (dh >= 1 ? offH[i][1] : 0u) + (dh >= 2 ? offH[i][2] : 0u) +
+                             offW[i][0] + (dw >= 1 ? offW[i][1] : 0u) + (dw >= 2 ? offW[i][2] : 0u);
+                asm volatile("" : "+v"(o));
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ab + o), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
             }
         } else {
             uint64_t abv = reinterpret_cast<uint64_t>(a_tile + koff * 2);
@@ -374,6 +392,7 @@ extern "C" int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_ta
     g.cT = T; g.cH = H; g.cW = W; g.cin = Cin; g.up_t = up_t; g.up_hw = up_hw;
     g.sT = up_t ? (T + 1) / 2 : T; g.sH = H >> up_hw; g.sW = W >> up_hw;
     g.mt = g.mh = g.mw = 1; g.bH = H; g.bW = W;
+    if ((int64_t)g.sT * g.sH * g.sW * ldx * 2 >= ((int64_t)1 << 32)) return HV_ERR_ARG;   // the gather uses 32-bit byte offsets (4 GiB source)
     return launch<F16T, true>(g, stream);
 }
 
@@ -394,5 +413,6 @@ extern "C" int hv_conv3d_causal_strided_f16(const void* x, int64_t ldx, const vo
     g.cT = T; g.cH = H; g.cW = W; g.cin = Cin; g.up_t = 0; g.up_hw = 0;
     g.sT = sT; g.sH = sH; g.sW = sW;
     g.mt = stride_t; g.mh = stride_h; g.mw = stride_w; g.bH = sH; g.bW = sW;
+    if ((int64_t)sT * sH * sW * ldx * 2 >= ((int64_t)1 << 32)) return HV_ERR_ARG;
     return launch<F16T, true>(g, stream);
 }
