@@ -113,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     // coordinate multipliers); the K loop only selects three of them with wave-uniform conditions and adds: no multiplies, clamps or
     // 64-bit arithmetic per K-tile (that arithmetic used to cost about as many issue cycles as the tile's MFMAs at BN = 128).
     uint32_t offT[4][3], offH[4][3], offW[4][3];
+    uint32_t tap_off[4] = {0u, 0u, 0u, 0u};       // byte offsets of the current tap's source rows (refreshed when the tap changes)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = i * 64 + srow;
@@ -173,12 +174,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             uint64_t abv = reinterpret_cast<uint64_t>(g.A + c0);
             asm volatile("" : "+s"(abv));
             const char* ab = reinterpret_cast<const char*>(abv);
+            if (c0 == 0) {      // a new tap (every cin/64 K-tiles): wave-uniform branch
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    // [0] = term of tap coordinate 0, [1] / [2] = increments to coordinates 1 / 2 (a select is "add or add nothing")
+                    tap_off[i] = offT[i][0] + (dt >= 1 ? offT[i][1] : 0u) + (dt >= 2 ? offT[i][2] : 0u) +
+                                 offH[i][0] + (dh >= 1 ? offH[i][1] : 0u) + (dh >= 2 ? offH[i][2] : 0u) +
+                                 offW[i][0] + (dw >= 1 ? offW[i][1] : 0u) + (dw >= 2 ? offW[i][2] : 0u);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // [0] = term of tap coordinate 0, [1] / [2] = increments to coordinates 1 / 2 (so a select is "add or add nothing")
-                uint32_t o = offT[i][0] + (dt >= 1 ? offT[i][1] : 0u) + (dt >= 2 ? offT[i][2] : 0u) +
-                             offH[i][0] + (dh >= 1 ? offH[i][1] : 0u) + (dh >= 2 ? offH[i][2] : 0u) +
-                             offW[i][0] + (dw >= 1 ? offW[i][1] : 0u) + (dw >= 2 ? offW[i][2] : 0u);
+                uint32_t o = tap_off[i];
                 asm volatile("" : "+v"(o));
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ab + o), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
             }
