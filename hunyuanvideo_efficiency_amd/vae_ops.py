@@ -40,10 +40,19 @@ def gemm_f16(a, w, bias=None, out=None, out_f32: bool = False, res=None, n: Opti
     return out
 
 
+def _conv_source_limit(x):
+    """The conv gather addresses its source with 32-bit byte offsets: one activation must stay below 4 GiB.  Every tile of the
+    reference's tiled decode/encode is far below that (largest: 1.09 GB); an untiled call on a large video is what can exceed it."""
+    if x.shape[0] * x.stride(0) * 2 >= 2 ** 32:
+        raise ValueError(f"activation of {x.shape[0] * x.stride(0) * 2 / 2**30:.1f} GiB exceeds the conv kernel's 4 GiB source limit: "
+                         "call vae.enable_tiling() (the reference's default for decode) or decode/encode a smaller clip")
+
+
 def conv3d_causal(x, w_taps, bias, T: int, H: int, W: int, cin: int, cout: int, up_t: bool = False, up_hw: bool = False,
                   res=None, out=None):
     """x: channels-last source rows [sT*sH*sW, >=cin]; returns [T*H*W, cout] fp16."""
     _chk(x, F16, "x"), _chk(w_taps, F16, "w_taps")
+    _conv_source_limit(x)
     assert w_taps.is_contiguous() and w_taps.numel() == cout * 27 * cin, (w_taps.shape, cout, cin)
     if out is None:
         out = torch.empty(T * H * W, cout, dtype=F16, device=x.device)
@@ -60,6 +69,7 @@ def conv3d_causal(x, w_taps, bias, T: int, H: int, W: int, cin: int, cout: int, 
 def conv3d_causal_strided(x, w_taps, bias, sT: int, sH: int, sW: int, cin: int, cout: int, stride=(1, 1, 1)):
     """DownsampleCausal3D conv: x channels-last [sT*sH*sW, >=cin] -> ([T*H*W, cout] fp16, T, H, W)."""
     _chk(x, F16, "x"), _chk(w_taps, F16, "w_taps")
+    _conv_source_limit(x)
     assert w_taps.is_contiguous() and w_taps.numel() == cout * 27 * cin, (w_taps.shape, cout, cin)
     st, sh, sw = (int(v) for v in stride)
     T, H, W = (sT - 1) // st + 1, (sH - 1) // sh + 1, (sW - 1) // sw + 1

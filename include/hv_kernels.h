@@ -138,7 +138,8 @@ int hv_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const vo
  * implicit GEMM; with up_t/up_hw the nearest upsample of UpsampleCausal3D.forward (:154-172: first frame x(1,2,2), others
  * x(2,2,2)) that precedes its conv is folded into the gather.  x: source [sT,sH,sW,Cin] (row stride ldx);
  * w_taps: [Cout][27][Cin] fp16 (tap = (dt*3 + dh)*3 + dw); out: [T*H*W, Cout]; res (nullable): out = res + f16(y)
- * (ResnetBlockCausal3D residual :413-415).  Cin % 64 == 0, Cout % 8 == 0 (callers zero-pad 16->64 and 3->8). */
+ * (ResnetBlockCausal3D residual :413-415).  Cin % 64 == 0, Cout % 8 == 0 (callers zero-pad 16->64 and 3->8).
+ * The source is addressed with 32-bit byte offsets: sT*sH*sW*ldx*2 must be < 4 GiB (HV_ERR_ARG otherwise). */
 int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_taps, const void* bias, void* out, int64_t ldo,
                          int T, int H, int W, int Cin, int Cout, int up_t, int up_hw, const void* res,
                          int64_t ld_res, hipStream_t stream);
