@@ -84,7 +84,7 @@ def _worker(rank, world, port, results):
         from hunyuanvideo_efficiency_amd.inference import parallelize_transformer_module
         from oracle import dit_ref as R
         E = R.Prec(True)
-        H, s_img, n_txt = 4, 96, 11
+        H, s_img, n_txt = (8 if world == 8 else 4), 96, 11        # world 8 = the driver's largest scaling point (24 heads / 8)
         s_loc = s_img // world
         bf = lambda t: t.to(torch.bfloat16)
         q, k, v = (bf(syn.hashed_uniform((1, s_img + n_txt, H, 128), f"ul.{n}", 5) * 1.7) for n in "qkv")
@@ -128,7 +128,8 @@ def _worker(rank, world, port, results):
                 f = (freqs_cos + 2 * freqs_sin).sum(-1).reshape(1, 1, T, Hh, Ww)
                 f = f.repeat_interleave(2, 3).repeat_interleave(2, 4)
                 return {"x": x * 3 + f}
-        for (T, Hl, Wl) in ((3, 8, 6), (3, 6, 8)):       # (H/2) % 2 == 0 -> split H ; else split W
+        shapes = ((3, 16, 6), (3, 6, 16)) if world == 8 else ((3, 8, 6), (3, 6, 8))
+        for (T, Hl, Wl) in shapes:       # (H/2) % P == 0 -> split H ; else split W
             x = syn.hashed_uniform((1, 16, T, Hl, Wl), "ul.x", 1)
             cos, sin = R.rope_tables([T, Hl // 2, Wl // 2], [16, 56, 56], 256.0)
             full = FakeTransformer().forward(x, None, freqs_cos=cos, freqs_sin=sin)["x"]
@@ -147,7 +148,7 @@ def _worker(rank, world, port, results):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_ulysses_exchange_and_sharding_gloo(world):
     port = 29600 + world + (os.getpid() % 200)
     mgr = mp.Manager()
