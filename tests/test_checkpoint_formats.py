@@ -142,3 +142,21 @@ def test_fp8_map_file(tmp_path):
     for i, k in enumerate(keys):
         assert mods[k].weight.dtype == torch.float8_e4m3fn
         assert abs(float(mods[k].fp8_scale) - 0.01 * (i + 1)) < 1e-3 * (i + 1)
+
+
+def test_vae_tile_parallel_plan_720p():
+    """Host logic of the tile-parallel VAE decode: the 84 tiles of a 720p x 129f latent are each assigned to exactly
+    one rank, identically on every rank, with a balanced load (longest-processing-time-first over the tile sizes)."""
+    from hunyuanvideo_efficiency_amd.vae import AutoencoderKLCausal3D
+    vae = AutoencoderKLCausal3D(block_out_channels=(32, 64, 128, 128), device="cpu")
+    vae.enable_tiling()
+    z4 = torch.zeros(16, 33, 90, 160)
+    views = list(vae._tile_views(z4))
+    assert len(views) == 84
+    costs = [v.shape[1] * v.shape[2] * v.shape[3] for v in views]
+    for world in (2, 3, 4, 8):
+        plan = vae._assign_tiles(costs, world)
+        assert sorted(k for p in plan for k in p) == list(range(84))
+        loads = [sum(costs[k] for k in p) for p in plan]
+        assert max(loads) <= 1.08 * (sum(costs) / world), (world, loads)
+        assert plan == vae._assign_tiles(costs, world)
