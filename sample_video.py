@@ -110,7 +110,10 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(a.seed)
     torch.cuda.synchronize()
     t0 = time.time()
-    common = dict(height=h, width=w, video_length=a.video_length, num_inference_steps=a.infer_steps, guidance_scale=a.cfg_scale,
+    def progress(i, t, latents):       # the reference shows a tqdm bar (pipeline_hunyuan_video.py:955-961); one line every 5 steps here
+        if rank == 0:
+            print(f"  step {i + 1}/{a.infer_steps}  t={float(t):.1f}  elapsed {time.time() - t0:.1f} s", flush=True)
+    common = dict(callback=progress, callback_steps=5, height=h, width=w, video_length=a.video_length, num_inference_steps=a.infer_steps, guidance_scale=a.cfg_scale,
                   embedded_guidance_scale=a.embedded_cfg_scale, generator=gen, freqs_cis=freqs, vae_ver=a.vae,
                   enable_tiling=a.vae_tiling, n_tokens=freqs[0].shape[0])
     if a.prompt is not None:
