@@ -39,40 +39,100 @@ def step_flops(s_img, s_txt, d=3072, n_double=20, n_single=40):
 
 
 def cpu_baseline(f_step, seconds_budget=30.0):
-    """Oracle (CPU port of the reference path, fp32 eager) on one double + one single block at full width
-    d=3072, S=1024+256 tokens; extrapolated to a full step by algorithmic FLOPs (stated as such)."""
+    """the oracle (CPU port of the reference path, fp32 eager, all host threads) timed on
+    (i) BASELINE.json configs[0] exactly (tiny DiT, one denoise step), (ii) one double + one single block at full width d=3072,
+    S=4,096+256 tokens - the leg `value` is FLOP-scaled from (stated as an extrapolation) - and (iii) one reduced VAE decoder
+    tile.  Bounded: about 10-30 s of CPU work on the GPU box's host cores."""
     import torch
     from hunyuanvideo_efficiency_amd import synthetic as syn
     from oracle import dit_ref as R
-    cfg = syn.DiTConfig(mm_double_blocks_depth=1, mm_single_blocks_depth=1)
-    d, s_img, s_txt = cfg.hidden_size, 1024, 256
-    gen_dev = "cuda" if torch.cuda.is_available() else "cpu"
-    sd = {}
-    for k, shp in syn.dit_param_shapes(cfg).items():
-        if k.startswith("double_blocks.0.") or k.startswith("single_blocks.0."):
-            sd[k] = syn.synth_param(k, shp, 0, gen_dev).cpu()
-    img = syn.hashed_uniform((1, s_img, d), "cpu.img", 0) * 1.7
-    txt = syn.hashed_uniform((1, s_txt, d), "cpu.txt", 0) * 1.7
-    vec = syn.hashed_uniform((1, d), "cpu.vec", 0) * 0.5
-    cos, sin = R.rope_tables([4, 16, 16], cfg.rope_dim_list, 256.0)
-    cu = torch.tensor([0, s_img + 11, s_img + s_txt], dtype=torch.int32)
+    from oracle import vae_ref as VR
     cores = torch.get_num_threads()
-    f_sample = 2 * (24 * d * d * (s_img + s_txt) + 4 * (s_img + s_txt) ** 2 * d)
-    reps, t0 = 0, time.perf_counter()
+    gen_dev = "cuda" if torch.cuda.is_available() else "cpu"
+    legs = {}
     with torch.no_grad():
+        # (i) config 1: tiny DiT (d=256, 1+1 blocks), 16x16x5 latent, one denoise step
+        tcfg = syn.tiny_config()
+        tsd = {k: syn.synth_param(k, shp, 0, "cpu") for k, shp in syn.dit_param_shapes(tcfg).items()}
+        x, ts, tm, ts2 = syn.synth_dit_inputs(tcfg, (5, 16, 16), 32, 11, seed=0)
+        rc, rs = R.rope_tables([5, 8, 8], tcfg.rope_dim_list, 256.0)
+        sig = R.flow_sigmas(1, 7.0)
+        g = torch.tensor([6016.0])
+        t0 = time.perf_counter()
+        v = R.dit_forward(tsd, tcfg, x, R.flow_timesteps(sig)[0:1], ts, tm, ts2, rc, rs, g, R.FP32)
+        R.euler_step(x, v, sig, 0)
+        legs["config1_tiny_step_s"] = time.perf_counter() - t0
+        # (ii) one double + one single block, d=3072, S=4096+256
+        cfg = syn.DiTConfig(mm_double_blocks_depth=1, mm_single_blocks_depth=1)
+        d, s_img, s_txt = cfg.hidden_size, 4096, 256
+        sd = {}
+        for k, shp in syn.dit_param_shapes(cfg).items():
+            if k.startswith("double_blocks.0.") or k.startswith("single_blocks.0."):
+                sd[k] = syn.synth_param(k, shp, 0, gen_dev).cpu()
+        img = syn.hashed_uniform((1, s_img, d), "cpu.img", 0) * 1.7
+        txt = syn.hashed_uniform((1, s_txt, d), "cpu.txt", 0) * 1.7
+        vec = syn.hashed_uniform((1, d), "cpu.vec", 0) * 0.5
+        cos, sin = R.rope_tables([4, 32, 32], cfg.rope_dim_list, 256.0)
+        cu = torch.tensor([0, s_img + 11, s_img + s_txt], dtype=torch.int32)
+        f_sample = 2 * (24 * d * d * (s_img + s_txt) + 4 * (s_img + s_txt) ** 2 * d)
+        reps, t0 = 0, time.perf_counter()
         while True:
             io, to = R.double_block(sd, "double_blocks.0.", img, txt, vec, cu, cos, sin, cfg.heads_num, R.FP32)
             R.single_block(sd, "single_blocks.0.", torch.cat([io, to], 1), vec, s_txt, cu, cos, sin, cfg.heads_num, R.FP32)
             reps += 1
             el = time.perf_counter() - t0
-            if el > seconds_budget * 0.5 or reps >= 8:
+            if el > seconds_budget * 0.5 or reps >= 4:
                 break
-    sec_per_sample = el / reps
-    cpu_flops = f_sample / sec_per_sample
+        sec_per_sample = el / reps
+        cpu_flops = f_sample / sec_per_sample
+        del sd, img, txt
+        # (iii) one reduced VAE decoder tile: channels (32,64,128,128), latent 5x16x16 -> [3,17,128,128]
+        boc = (32, 64, 128, 128)
+        vsd = syn.synth_vae_state_dict(boc, seed=0)
+        z = syn.hashed_uniform((1, 16, 5, 16, 16), "cpu.z", 0) * 1.7
+        t0 = time.perf_counter()
+        VR.decode_tile(vsd, z, boc, VR.FP32)
+        legs["vae_reduced_tile_s"] = time.perf_counter() - t0
     return {"value": cpu_flops / f_step, "unit": "denoise-steps/s (FLOP-scaled extrapolation from the sample)",
             "cores": cores, "kind": "port",
             "sample": f"oracle fp32: 1 double + 1 single block, d=3072, S={s_img}+{s_txt}, {reps} reps, "
-                      f"{sec_per_sample:.2f} s each = {cpu_flops / 1e12:.3f} TFLOP/s"}
+                      f"{sec_per_sample:.2f} s each = {cpu_flops / 1e12:.3f} TFLOP/s; config 1 (tiny DiT, 1 step) "
+                      f"{legs['config1_tiny_step_s']:.3f} s"
+                      f"; reduced VAE decoder tile (32,64,128,128) 5x16x16 latent {legs['vae_reduced_tile_s']:.2f} s",
+            **legs}
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` from a cold shell (no RANK in the environment): start N rank processes, one per GPU, as fresh
+    children of THIS process - which never imports torch or touches HIP, so nothing that initialised the GPU ever execs - with
+    the torchrun environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; the reference's recipe is
+    `torchrun --nproc_per_node=8 sample_video.py ...`, scripts/run_sample_video_multigpu.sh:35).  Rank 0 inherits stdout and
+    prints the one JSON line; returns non-zero if any rank fails (the others are then terminated by exact PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for pr in list(pending):
+            code = pr.poll()
+            if code is None:
+                continue
+            pending.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:      # one rank died: the rest would hang in a collective
+                    other.terminate()
+        time.sleep(0.2)
+    return rc
 
 
 def main():
@@ -91,13 +151,17 @@ def main():
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-by-`value`) VAE tiled decode of the same video")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # cold shell: become the launcher (before torch is imported; this process never touches the GPU)
+        raise SystemExit(launch_ranks(a.gpus))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or a.force_sp:
@@ -106,7 +170,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from hunyuanvideo_efficiency_amd import _lib, ops, synthetic as syn
-    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.builders import build_model
     from hunyuanvideo_efficiency_amd.diffusion.schedulers import FlowMatchDiscreteScheduler
     from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
     _lib.load()
@@ -198,14 +262,21 @@ def main():
         avg_ms = sum(att_ms) / max(len(att_ms), 1)
         avg_flop = sum(att_flop) / max(len(att_flop), 1)
         achieved = avg_flop / (avg_ms * 1e-3) / 1e12 if att_ms else 0.0
-        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (same kernel, same shape; FETCH_SIZE x2 gfx950 correction)
-        traffic, traffic_note = None, None
-        tf = os.path.join(ROOT, "profiles", "r01", "attn_traffic.json")
-        if world == 1 and a.workload == "720p129f" and os.path.exists(tf):
-            tj = json.load(open(tf))
-            traffic = tj["traffic_bytes_per_launch"]
-            traffic_note = ("bytes/launch from profiles/r01/attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes); "
-                            f"algorithmic {tj['algorithmic_bytes_per_launch']:.3e} B; counter includes Infinity-Cache hits (per-XCD K/V re-streams)")
+        # HBM-side bytes per launch: NOT collected by this run - cited from the committed rocprofv3 PMC passes of the same kernel
+        # and shape (separate --pmc passes; FETCH_SIZE x2 gfx950 correction), newest round first; `traffic_source` names the file
+        traffic, traffic_note, traffic_source = None, None, None
+        if world == 1 and a.workload == "720p129f":
+            for rnd in ("r02", "r01"):
+                tf = os.path.join(ROOT, "profiles", rnd, "attn_traffic.json")
+                if os.path.exists(tf):
+                    tj = json.load(open(tf))
+                    traffic = tj["traffic_bytes_per_launch"]
+                    traffic_source = f"profiles/{rnd}/attn_traffic.json"
+                    traffic_note = (f"cited, not live: bytes/launch of kernel {tj.get('kernel', 'attn_fwd_kernel_v2')} from {traffic_source} "
+                                    f"(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes); algorithmic "
+                                    f"{tj['algorithmic_bytes_per_launch']:.3e} B; the counter includes Infinity-Cache hits "
+                                    "(per-XCD K/V re-streams)")
+                    break
         out = {
             "metric": ("denoise-steps/sec (" + {"720p129f": "720x1280x129f", "544p65f": "544x960x65f", "720p257f": "720x1280x257f"}.get(a.workload, a.workload)
                        + ", HunyuanVideo DiT 20+40 blocks, " + ("bf16 compute, fp8 e4m3 weights)" if a.use_fp8 else "bf16)")) if not tiny else "denoise-steps/sec (tiny)",
@@ -222,7 +293,7 @@ def main():
             "step_mfma_frac": f_step / (ms_per_step * 1e-3) / (world * PEAK_BF16_TFLOPS * 1e12),
             "roofline": {"kernel": "attn_fwd_kernel (hv_attn_fwd_bf16, main segment)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note,
                          "launches": len(att_ms), "avg_launch_ms": avg_ms, "flop_per_launch": avg_flop},
         }
         if world == 1 and not a.no_cpu_baseline:

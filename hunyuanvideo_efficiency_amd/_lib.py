@@ -1,8 +1,13 @@
-"""ctypes binding of libhv_kernels.so (the C ABI declared in include/hv_kernels.h).
+"""Bindings of the HIP extension.
 
-There is NO fallback: if the shared library is missing or a symbol is absent the import of the
-compute path raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
-``make -C hunyuanvideo_efficiency_amd/csrc``.
+* `libhv_kernels.so`   - the C ABI declared in include/hv_kernels.h (hipcc, gfx950).  `load()` binds it with ctypes: used by the
+  symbol/ABI checks (tests/test_capi_cpu.py) and by any host that is not PyTorch.
+* `libhv_torch_ops.so` - csrc/hv_torch_ops.cpp: TORCH_LIBRARY(hv, m) + TORCH_LIBRARY_IMPL(hv, CUDA, m), one custom op per C-ABI
+  entry point (`torch.ops.hv.gemm_bf16`, `torch.ops.hv.attn_fwd_bf16`, ...), each launching on the current HIP stream of its
+  tensors' device.  `call()` / `host()` are the product path: ops.py and vae_ops.py reach every kernel through torch.ops.hv.
+
+There is NO fallback: if a shared library is missing or a symbol is absent the import of the compute path raises.  Build with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C hunyuanvideo_efficiency_amd/csrc``.
 """
 from __future__ import annotations
 
@@ -11,7 +16,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhv_kernels.so")
-ABI_VERSION = 1
+TORCH_OPS_PATH = os.path.join(_HERE, "lib", "libhv_torch_ops.so")
+ABI_VERSION = 2
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -31,6 +37,7 @@ SIGNATURES = {
     "hv_patchify_f32_bf16": [_p, _p, _i, _i, _i, _i, _p],
     "hv_unpatchify_bf16": [_p, _p, _i, _i, _i, _i, _l, _p],
     "hv_euler_step_f32": [_p, _p, _f, _l, _p],
+    "hv_euler_step_f32_f32": [_p, _p, _f, _l, _p],
     "hv_masked_mean_bf16": [_p, _p, _p, _i, _i, _p],
     "hv_broadcast_row_bf16": [_p, _p, _l, _i, _l, _p],
     "hv_copy3d_bf16": [_p, _p, _i, _l, _i, _l, _l, _l, _l, _p],
@@ -85,3 +92,43 @@ def check(code: int, what: str):
     if code != 0:
         raise HVKernelError(f"{what} failed with code {code} "
                             f"({'bad argument' if code == -1 else 'launch failure' if code == -2 else 'unknown'})")
+
+
+_hv = None
+
+
+def torch_ops():
+    """Load (once) libhv_torch_ops.so and return the `torch.ops.hv` namespace; raises HVKernelError if it is not built."""
+    global _hv
+    if _hv is not None:
+        return _hv
+    import torch
+    if not os.path.exists(TORCH_OPS_PATH):
+        raise HVKernelError(
+            f"{TORCH_OPS_PATH} is missing: the PyTorch custom-op library is not built (run __graft_entry__.build()). "
+            "hunyuanvideo_efficiency_amd has no CPU or eager fallback.")
+    torch.ops.load_library(TORCH_OPS_PATH)
+    hv = torch.ops.hv
+    v = int(hv.abi_version())
+    if v != ABI_VERSION:
+        raise HVKernelError(f"libhv_torch_ops / libhv_kernels ABI {v} != expected {ABI_VERSION}: rebuild the extension")
+    for name in SIGNATURES:
+        if not hasattr(hv, name[len("hv_"):]):
+            raise HVKernelError(f"{TORCH_OPS_PATH} does not register torch.ops.hv.{name[len('hv_'):]}")
+    _hv = hv
+    return hv
+
+
+def call(name: str, *args):
+    """torch.ops.hv.<name>(*args): tensors (or None), ints, floats, int lists - see the schema in csrc/hv_torch_ops.cpp.
+    A non-zero kernel return code, a CPU tensor or a tensor on another GPU surfaces as HVKernelError."""
+    op = getattr(torch_ops(), name)
+    try:
+        return op(*args)
+    except (RuntimeError, NotImplementedError) as e:
+        raise HVKernelError(f"hv::{name}: {str(e).splitlines()[0]}") from e
+
+
+def host(name: str, *args) -> int:
+    """Pure host queries of the ABI (no tensors): abi_version, attn_workspace_bytes, attn_suggest_splits."""
+    return int(getattr(torch_ops(), name)(*args))

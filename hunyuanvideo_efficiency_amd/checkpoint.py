@@ -79,6 +79,12 @@ def resolve_dit_weight(dit_weight, pretrained_model_path=None, model_resolution:
     return model_path, bare
 
 
+def resolve_dit_path(args, pretrained_model_path=None) -> Path:
+    """The checkpoint file load_state_dict(args, ...) will read (so `<file>_map.pt` can be located before loading)."""
+    return resolve_dit_weight(getattr(args, "dit_weight", None), pretrained_model_path, getattr(args, "model_resolution", "540p"),
+                              getattr(args, "load_key", "module"))[0]
+
+
 def load_state_dict(args, model, pretrained_model_path=None):
     """Mirror of Inference.load_state_dict(args, model, pretrained_model_path) (inference.py:279-354); args carries
     .dit_weight, .load_key and .model_resolution."""

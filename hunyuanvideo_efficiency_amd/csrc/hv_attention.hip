@@ -334,6 +334,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     *reinterpret_cast<u32x2*>(o + row * so + head * D + d4 * 4) = w2;
 }
 
+HvPerDeviceOnce g_attn_lds_once;
+
 }  // namespace
 
 extern "C" int64_t hv_attn_workspace_bytes(int n_q, int n_kv, int n_heads) {
@@ -356,12 +358,7 @@ extern "C" int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.n_q = n_q; a.n_kv = n_kv; a.n_heads = n_heads;
     a.n_qtiles = (n_q + QTILE - 1) / QTILE;
     a.scale_log2e = scale * 1.4426950408889634f;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
-            return HV_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (hv_set_max_lds(g_attn_lds_once, (const void*)attn_fwd_kernel_v2, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
     // Load balance: workgroups are equal-cost items on 256 CUs; with only a few rounds (e.g. 3 heads per rank under Ulysses-8:
     // 1395 items = 5.45 rounds -> 6) a partially filled last round costs a whole item.  Splitting the key range in two makes
     // the items half as long (2790 items = 10.9 -> 11 half-rounds = 5.5): taken when it shortens the makespan by > 3 %.
@@ -410,12 +407,7 @@ extern "C" int hv_attn_partial_bf16(const void* q, const void* k, const void* v,
     a.part_o = (float*)part_o + (int64_t)slot * n_q * n_heads * D;
     a.part_ml = (float*)part_ml + (int64_t)slot * n_q * n_heads * 2;
     a.partial = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
-            return HV_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (hv_set_max_lds(g_attn_lds_once, (const void*)attn_fwd_kernel_v2, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
     attn_fwd_kernel_v2<<<dim3((unsigned)(a.n_qtiles * n_heads), (unsigned)splits), dim3(512), ATT_LDS, stream>>>(a);
     return hv_check_launch();
 }

@@ -66,6 +66,19 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
+// Raising a kernel's dynamic-LDS limit is a per-DEVICE attribute: one process may drive several GPUs, so the "already done"
+// flag is kept per device ordinal (hipGetDevice is a thread-local read, no driver call).
+struct HvPerDeviceOnce { bool done[64] = {}; };
+static inline int hv_set_max_lds(HvPerDeviceOnce& once, const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return HV_ERR_LAUNCH;
+    if (!once.done[dev]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return HV_ERR_LAUNCH;
+        once.done[dev] = true;
+    }
+    return HV_OK;
+}
+
 static inline int hv_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? HV_OK : HV_ERR_LAUNCH;

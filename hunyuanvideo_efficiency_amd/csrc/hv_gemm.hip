@@ -106,8 +106,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
 
     // ---- per-thread staging addresses: 4 DMA pieces per operand per K-tile, each 512 thr x 16 B = 64 rows
     const int srow = tid >> 3, scp = tid & 7;  // row within a 64-row piece, 16-B chunk position in LDS
-    const uint16_t* a_src[4];
-    const uint16_t* w_src[WPIECES];
     // conv: the source row of tap (dt,dh,dw) separates into a frame, a line and a column term.  All nine terms of each staged row
     // are formed ONCE here as byte offsets (replicate/causal padding = the clamps, nearest upsample = the halvings, stride = the
     // coordinate multipliers); the K loop only selects three of them with wave-uniform conditions and adds: no multiplies, clamps or
@@ -136,16 +134,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             offT[i][0] = aT[0]; offT[i][1] = aT[1] - aT[0]; offT[i][2] = aT[2] - aT[1];
             offH[i][0] = aH[0]; offH[i][1] = aH[1] - aH[0]; offH[i][2] = aH[2] - aH[1];
             offW[i][0] = aW[0]; offW[i][1] = aW[1] - aW[0]; offW[i][2] = aW[2] - aW[1];
-            a_src[i] = g.A;
-        } else {
-            a_src[i] = g.A + (int64_t)ar * g.lda + ((scp ^ swz_a(row)) << 3);
         }
-    }
-#pragma unroll
-    for (int i = 0; i < WPIECES; ++i) {
-        const int row = i * 64 + srow;
-        const int wr = min(n0 + row, g.N - 1);
-        w_src[i] = g.W + (int64_t)wr * g.ldw + ((scp ^ swz_w(row)) << 3);
     }
     const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;  // this wave's 1 KiB slice of each piece; scalar: the DMA
                                                                         // destination goes through M0, no VALU/readfirstlane per piece
@@ -321,12 +310,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
 
 template <typename DT, bool CONV, int BN>
 int launch_bn(GemmArgs& g, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_kernel<DT, CONV, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<BN>()) != hipSuccess)
-            return HV_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static HvPerDeviceOnce once;     // one per template instantiation
+    if (hv_set_max_lds(once, (const void*)gemm_kernel<DT, CONV, BN>, lds_bytes<BN>()) != HV_OK) return HV_ERR_LAUNCH;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     gemm_kernel<DT, CONV, BN><<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), lds_bytes<BN>(), stream>>>(g);

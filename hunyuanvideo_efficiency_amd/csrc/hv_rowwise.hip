@@ -286,6 +286,26 @@ extern "C" int hv_euler_step_f32(float* sample, const void* model_out_bf16, floa
     return hv_check_launch();
 }
 
+// same update with an fp32 velocity (the reference upcasts model_output to fp32, :239; a caller that hands in fp32 keeps it)
+__global__ __launch_bounds__(256) void euler_f32_kernel(float* __restrict__ s, const float* __restrict__ v, float dt, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 a = *reinterpret_cast<float4*>(s + i);
+        const float4 b = *reinterpret_cast<const float4*>(v + i);
+        a.x += b.x * dt, a.y += b.y * dt, a.z += b.z * dt, a.w += b.w * dt;
+        *reinterpret_cast<float4*>(s + i) = a;
+    } else {
+        for (int64_t j = i; j < n; ++j) s[j] += v[j] * dt;
+    }
+}
+
+extern "C" int hv_euler_step_f32_f32(float* sample, const float* model_out_f32, float dt, int64_t n, hipStream_t stream) {
+    if (!sample || !model_out_f32 || n < 0) return HV_ERR_ARG;
+    if (n == 0) return HV_OK;
+    euler_f32_kernel<<<dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, stream>>>(sample, model_out_f32, dt, n);
+    return hv_check_launch();
+}
+
 // masked mean over tokens (token_refiner.py:222-228): out[d] = sum_l x[l][d]*mask[l] / sum_l mask[l], fp32 -> bf16 out
 __global__ __launch_bounds__(256) void masked_mean_kernel(const bf16_t* __restrict__ x, const int* __restrict__ mask,
                                                            bf16_t* __restrict__ out, int L, int D) {

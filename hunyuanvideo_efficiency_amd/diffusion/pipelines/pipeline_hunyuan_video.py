@@ -109,7 +109,8 @@ class HunyuanVideoPipeline:
                 callback(i // getattr(self.scheduler, "order", 1), t, latents)
         # decode tail (:1047-1092)
         if output_type == "latent":
-            image = latents
+            # the reference applies the same post-scale to raw latents (:1088-1092): (x / 2 + 0.5).clamp(0, 1)
+            image = (latents / 2 + 0.5).clamp(0, 1)
         else:
             if hasattr(self.vae.config, "shift_factor") and self.vae.config.shift_factor:
                 latents = latents / self.vae.config.scaling_factor + self.vae.config.shift_factor

@@ -79,10 +79,17 @@ class FlowMatchDiscreteScheduler:
         if self.step_index is None:
             self._init_step_index(timestep)
         dt = float(self.sigmas[self.step_index + 1] - self.sigmas[self.step_index])
-        # upcast (a no-op from step 2 on: latents are fp32 after the first step); out of place like the reference
-        prev = sample.to(torch.float32).clone() if sample.dtype == torch.float32 else sample.to(torch.float32)
-        mo = model_output if model_output.dtype == torch.bfloat16 else model_output.to(torch.bfloat16)
-        ops.euler_step_(prev.contiguous(), mo.contiguous(), dt)
+        # upcast (a no-op from step 2 on: latents are fp32 after the first step); out of place like the reference (:236-242).
+        # `prev` must be a fresh CONTIGUOUS buffer before the in-place kernel: .to()/.clone() keep a permuted sample's strides,
+        # and a later .contiguous() would update a temporary and silently drop the step.
+        prev = sample.to(torch.float32).contiguous()
+        if prev.data_ptr() == sample.data_ptr():
+            prev = prev.clone()
+        if model_output.dtype == torch.bfloat16:
+            ops.euler_step_(prev, model_output.contiguous(), dt)
+        else:
+            # the reference upcasts the model output to fp32 (:239); a non-bf16 output keeps that precision here
+            ops.euler_step_f32_(prev, model_output.to(torch.float32).contiguous(), dt)
         self._step_index += 1
         if not return_dict:
             return (prev,)

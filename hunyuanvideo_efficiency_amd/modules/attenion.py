@@ -13,24 +13,23 @@ import torch
 from .. import ops
 
 BF16 = torch.bfloat16
-_nvalid_cache = {}
-
-
 def n_valid_text(text_mask: torch.Tensor) -> int:
-    """Number of valid text tokens of sample 0 (text_mask.sum(dim=1), attenion.py:45).  One host read per distinct
-    mask tensor (the pipeline passes the same tensor every step); the mask must be a prefix mask, which is what
-    right-padded tokenisation produces and what get_cu_seqlens itself assumes."""
-    key = (text_mask.data_ptr(), text_mask._version, tuple(text_mask.shape), str(text_mask.device))
-    hit = _nvalid_cache.get(key)
-    if hit is not None:
-        return hit
+    """Number of valid text tokens of sample 0 (text_mask.sum(dim=1), attenion.py:45).  One host read per mask tensor
+    OBJECT (the pipeline passes the same tensor every step): the count is stashed on the tensor itself together with its
+    `_version`, never keyed on its address - a freed mask's address is recycled by the next mask, which must not inherit
+    the previous prompt's count.  The mask must be a prefix mask, which is what right-padded tokenisation produces and
+    what get_cu_seqlens itself assumes."""
+    hit = getattr(text_mask, "_hv_n_valid", None)
+    if hit is not None and hit[0] == text_mask._version:
+        return hit[1]
     m = text_mask[0].to("cpu").to(torch.int64)
     n = int(m.sum())
     if not bool((m[:n] != 0).all()):
         raise NotImplementedError("text_mask must be a prefix mask (valid tokens first)")
-    if len(_nvalid_cache) > 64:
-        _nvalid_cache.clear()
-    _nvalid_cache[key] = n
+    try:
+        text_mask._hv_n_valid = (text_mask._version, n)
+    except (AttributeError, RuntimeError):      # exotic tensor subclasses: just recompute next time
+        pass
     return n
 
 

@@ -1,6 +1,7 @@
-"""Tensor-level wrappers over the C ABI (include/hv_kernels.h).  torch supplies device memory and the
-current HIP stream only; every arithmetic operation is a hand-written gfx950 kernel.  All wrappers
-raise if given a non-GPU tensor: there is no CPU path in the product."""
+"""Tensor-level wrappers over the PyTorch custom ops `torch.ops.hv.*` (csrc/hv_torch_ops.cpp: one op per C-ABI entry point of
+include/hv_kernels.h, registered with TORCH_LIBRARY(hv, m) for the CUDA(=HIP) dispatch key).  torch supplies device memory and
+the current HIP stream only; every arithmetic operation is a hand-written gfx950 kernel.  All wrappers raise if given a
+non-GPU tensor: there is no CPU path in the product."""
 from __future__ import annotations
 
 from typing import Optional
@@ -12,14 +13,6 @@ from . import _lib
 BF16 = torch.bfloat16
 ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
 PROFILE_ATTN = None  # set to a list by bench.py to collect (start_event, end_event, n_q, n_kv, heads) per launch
-
-
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
-
-
-def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
 
 
 def _chk(t: torch.Tensor, dtype, name: str, last_contig: bool = True):
@@ -60,8 +53,8 @@ def ln_modulate(x, shift=None, scale=None, out=None, eps: float = 1e-6, affine: 
         if t is not None:
             _chk(t, BF16, n)
             assert t.numel() == d and t.is_contiguous(), f"{n} must be a contiguous [{d}] vector (batch 1)"
-    _lib.check(_lib.load().hv_ln_modulate_bf16(_ptr(x), _ptr(shift), _ptr(scale), _ptr(out), m, d, ldx, ldo, eps,
-                                               1 if affine else 0, _stream()), "hv_ln_modulate_bf16")
+    _lib.call("ln_modulate_bf16", x, shift, scale, out, m, d, ldx, ldo, eps,
+                                               1 if affine else 0)
     return out
 
 
@@ -73,8 +66,8 @@ def qknorm_rope_(qkv, q_weight, k_weight, cos, sin, n_rope: int, n_heads: int, k
     if n_rope > 0:
         _chk(cos, torch.float32, "cos"), _chk(sin, torch.float32, "sin")
         assert cos.is_contiguous() and sin.is_contiguous() and cos.shape[-1] == 128 and cos.shape[0] >= n_rope
-    _lib.check(_lib.load().hv_qknorm_rope_bf16(_ptr(qkv), _ptr(q_weight), _ptr(k_weight), _ptr(cos), _ptr(sin), n,
-                                               n_rope, n_heads, 128, ld, k_offset, eps, _stream()), "hv_qknorm_rope_bf16")
+    _lib.call("qknorm_rope_bf16", qkv, q_weight, k_weight, cos, sin, n,
+                                               n_rope, n_heads, 128, ld, k_offset, eps)
     return qkv
 
 
@@ -105,8 +98,8 @@ def gemm(a, w, bias=None, out=None, act: int = ACT_NONE, n_split: int = 0, out1=
         _chk(res, BF16, "res")
         mr, nr, ld_res = _rows(res, "res")
         assert mr == m and nr == n
-    _lib.check(_lib.load().hv_gemm_bf16(_ptr(a), lda, _ptr(w), ldw, _ptr(bias), m, n, k, _ptr(out), ld0, act, n0,
-                                        _ptr(out1), ld1, act1, _ptr(gate), _ptr(res), ld_res, _stream()), "hv_gemm_bf16")
+    _lib.call("gemm_bf16", a, lda, w, ldw, bias, m, n, k, out, ld0, act, n0,
+                                        out1, ld1, act1, gate, res, ld_res)
     return out
 
 
@@ -123,9 +116,8 @@ def linear_smallm(x, w, bias=None, silu_in: bool = False, silu_out: bool = False
     if addend is not None:
         _chk(addend, BF16, "addend")
         assert addend.shape == out.shape and addend.stride() == out.stride()
-    _lib.check(_lib.load().hv_linear_smallm_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(addend), _ptr(out), m, n, k, ldx, ldo,
-                                                 (1 if silu_in else 0) | (2 if silu_out else 0), _stream()),
-               "hv_linear_smallm_bf16")
+    _lib.call("linear_smallm_bf16", x, w, bias, addend, out, m, n, k, ldx, ldo,
+                                                 (1 if silu_in else 0) | (2 if silu_out else 0))
     return out
 
 
@@ -137,7 +129,7 @@ def _attn_workspace(n_q, n_kv, n_heads, device):
     n_wg = ((n_q + 255) // 256) * n_heads
     if n_wg >= 16 * 256 or n_kv < 64 * 64:
         return None
-    need = int(_lib.load().hv_attn_workspace_bytes(n_q, n_kv, n_heads))
+    need = int(_lib.host("attn_workspace_bytes", n_q, n_kv, n_heads))
     key = str(device)
     ws = _attn_ws.get(key)
     if ws is None or ws.numel() < need:
@@ -160,9 +152,9 @@ def attn_fwd(q, k, v, out, n_heads: int, scale: Optional[float] = None, kv_split
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     ws = _attn_workspace(n_q, n_kv, n_heads, q.device) if kv_split_workspace else None
-    _lib.check(_lib.load().hv_attn_fwd_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), q.stride(0), k.stride(0), v.stride(0),
-                                            out.stride(0), n_q, n_kv, n_heads, 128, scale, _ptr(ws),
-                                            0 if ws is None else ws.numel(), _stream()), "hv_attn_fwd_bf16")
+    _lib.call("attn_fwd_bf16", q, k, v, out, q.stride(0), k.stride(0), v.stride(0),
+                                            out.stride(0), n_q, n_kv, n_heads, 128, scale, ws,
+                                            0 if ws is None else ws.numel())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, n_q, n_kv, n_heads))
@@ -180,7 +172,7 @@ class AttnPartials:
 
 
 def attn_suggest_splits(n_q: int, n_kv: int, n_heads: int) -> int:
-    return int(_lib.load().hv_attn_suggest_splits(n_q, n_kv, n_heads))
+    return int(_lib.host("attn_suggest_splits", n_q, n_kv, n_heads))
 
 
 def attn_partial(q, k, v, parts: AttnPartials, n_heads: int, splits: int = 1, scale: Optional[float] = None):
@@ -196,9 +188,8 @@ def attn_partial(q, k, v, parts: AttnPartials, n_heads: int, splits: int = 1, sc
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.load().hv_attn_partial_bf16(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), n_q, n_kv, n_heads,
-                                                128, scale, _ptr(parts.o), _ptr(parts.ml), parts.n_slots, parts.used, splits,
-                                                _stream()), "hv_attn_partial_bf16")
+    _lib.call("attn_partial_bf16", q, k, v, q.stride(0), k.stride(0), v.stride(0), n_q, n_kv, n_heads,
+                                                128, scale, parts.o, parts.ml, parts.n_slots, parts.used, splits)
     if prof is not None:
         e1.record()
         prof.append((e0, e1, n_q, n_kv, n_heads))
@@ -209,8 +200,8 @@ def attn_merge(parts: AttnPartials, out):
     """Fold the used slots into normalised bf16 rows out[n_q, >= H*128] (hv_attn_merge_bf16)."""
     _chk(out, BF16, "out")
     assert out.dim() == 2 and out.shape[0] == parts.n_q and parts.used >= 1
-    _lib.check(_lib.load().hv_attn_merge_bf16(_ptr(parts.o), _ptr(parts.ml), _ptr(out), out.stride(0), parts.n_q, parts.n_heads,
-                                              parts.used, _stream()), "hv_attn_merge_bf16")
+    _lib.call("attn_merge_bf16", parts.o, parts.ml, out, out.stride(0), parts.n_q, parts.n_heads,
+                                              parts.used)
     return out
 
 
@@ -221,7 +212,7 @@ def patchify(x_f32, out=None):
     c, t, h, w = x_f32.shape
     if out is None:
         out = torch.empty(t * (h // 2) * (w // 2), c * 4, dtype=BF16, device=x_f32.device)
-    _lib.check(_lib.load().hv_patchify_f32_bf16(_ptr(x_f32), _ptr(out), c, t, h, w, _stream()), "hv_patchify_f32_bf16")
+    _lib.call("patchify_f32_bf16", x_f32, out, c, t, h, w)
     return out
 
 
@@ -230,15 +221,21 @@ def unpatchify(y, c: int, t: int, h: int, w: int, out=None):
     assert y.dim() == 2
     if out is None:
         out = torch.empty(c, t, h, w, dtype=BF16, device=y.device)
-    _lib.check(_lib.load().hv_unpatchify_bf16(_ptr(y), _ptr(out), c, t, h, w, y.stride(0), _stream()), "hv_unpatchify_bf16")
+    _lib.call("unpatchify_bf16", y, out, c, t, h, w, y.stride(0))
     return out
 
 
 def euler_step_(sample_f32, model_out_bf16, dt: float):
     _chk(sample_f32, torch.float32, "sample"), _chk(model_out_bf16, BF16, "model_out")
     assert sample_f32.is_contiguous() and model_out_bf16.is_contiguous() and sample_f32.numel() == model_out_bf16.numel()
-    _lib.check(_lib.load().hv_euler_step_f32(_ptr(sample_f32), _ptr(model_out_bf16), float(dt), sample_f32.numel(),
-                                             _stream()), "hv_euler_step_f32")
+    _lib.call("euler_step_f32", sample_f32, model_out_bf16, float(dt), sample_f32.numel())
+    return sample_f32
+
+
+def euler_step_f32_(sample_f32, model_out_f32, dt: float):
+    _chk(sample_f32, torch.float32, "sample"), _chk(model_out_f32, torch.float32, "model_out")
+    assert sample_f32.is_contiguous() and model_out_f32.is_contiguous() and sample_f32.numel() == model_out_f32.numel()
+    _lib.call("euler_step_f32_f32", sample_f32, model_out_f32, float(dt), sample_f32.numel())
     return sample_f32
 
 
@@ -248,16 +245,14 @@ def masked_mean(x, mask_i32=None):
     out = torch.empty(x.shape[1], dtype=BF16, device=x.device)
     if mask_i32 is not None:
         _chk(mask_i32, torch.int32, "mask")
-    _lib.check(_lib.load().hv_masked_mean_bf16(_ptr(x), _ptr(mask_i32), _ptr(out), x.shape[0], x.shape[1], _stream()),
-               "hv_masked_mean_bf16")
+    _lib.call("masked_mean_bf16", x, mask_i32, out, x.shape[0], x.shape[1])
     return out
 
 
 def broadcast_row_(src, dst):
     _chk(src, BF16, "src"), _chk(dst, BF16, "dst")
     assert dst.dim() == 2 and src.numel() == dst.shape[1]
-    _lib.check(_lib.load().hv_broadcast_row_bf16(_ptr(src), _ptr(dst), dst.shape[0], dst.shape[1], dst.stride(0), _stream()),
-               "hv_broadcast_row_bf16")
+    _lib.call("broadcast_row_bf16", src, dst, dst.shape[0], dst.shape[1], dst.stride(0))
     return dst
 
 
@@ -265,8 +260,7 @@ def timestep_embedding(t_f32, dim: int = 256, max_period: float = 10000.0):
     _chk(t_f32, torch.float32, "t")
     t_f32 = t_f32.reshape(-1).contiguous()
     out = torch.empty(t_f32.numel(), dim, dtype=BF16, device=t_f32.device)
-    _lib.check(_lib.load().hv_timestep_embedding_bf16(_ptr(t_f32), _ptr(out), t_f32.numel(), dim, max_period, _stream()),
-               "hv_timestep_embedding_bf16")
+    _lib.call("timestep_embedding_bf16", t_f32, out, t_f32.numel(), dim, max_period)
     return out
 
 
@@ -276,8 +270,7 @@ def fp8_dequant(w8, scale_bf16, out_bf16):
         raise _lib.HVKernelError("fp8_dequant: expected a float8_e4m3fn GPU tensor")
     _chk(scale_bf16, BF16, "scale"), _chk(out_bf16, BF16, "out")
     assert w8.is_contiguous() and out_bf16.is_contiguous() and out_bf16.numel() == w8.numel()
-    _lib.check(_lib.load().hv_fp8_dequant_bf16(_ptr(w8), _ptr(scale_bf16), _ptr(out_bf16), w8.numel(), _stream()),
-               "hv_fp8_dequant_bf16")
+    _lib.call("fp8_dequant_bf16", w8, scale_bf16, out_bf16, w8.numel())
     return out_bf16
 
 
@@ -285,6 +278,5 @@ def copy3d(src, dst, n_batch: int, rows: int, cols: int, src_bs: int, src_ld: in
     """dst[b][r][:cols] = src[b][r][:cols] with explicit element strides; src/dst are any bf16 GPU tensors whose
     data_ptr() is element (0,0,0) of the region."""
     _chk(src, BF16, "src", False), _chk(dst, BF16, "dst", False)
-    _lib.check(_lib.load().hv_copy3d_bf16(_ptr(src), _ptr(dst), n_batch, rows, cols, src_bs, src_ld, dst_bs, dst_ld,
-                                          _stream()), "hv_copy3d_bf16")
+    _lib.call("copy3d_bf16", src, dst, n_batch, rows, cols, src_bs, src_ld, dst_bs, dst_ld)
     return dst

@@ -1,23 +1,22 @@
 """Tensor-level wrappers over the VAE-decode entry points of the C ABI (include/hv_kernels.h).  fp16, channels-last."""
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional, Sequence
 
 import torch
 
 from . import _lib
-from .ops import _chk, _ptr, _stream
+from .ops import _chk
 
 F16 = torch.float16
 
 
 def _i64x4(v: Sequence[int]):
-    return (C.c_int64 * 4)(*[int(x) for x in v])
+    return [int(x) for x in v]
 
 
 def _i32x4(v: Sequence[int]):
-    return (C.c_int * 4)(*[int(x) for x in v])
+    return [int(x) for x in v]
 
 
 def gemm_f16(a, w, bias=None, out=None, out_f32: bool = False, res=None, n: Optional[int] = None, k: Optional[int] = None):
@@ -35,8 +34,8 @@ def gemm_f16(a, w, bias=None, out=None, out_f32: bool = False, res=None, n: Opti
     if res is not None:
         _chk(res, F16, "res")
         ld_res = res.stride(0)
-    _lib.check(_lib.load().hv_gemm_f16(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), m, n, k, _ptr(out), out.stride(0),
-                                       1 if out_f32 else 0, _ptr(res), ld_res, _stream()), "hv_gemm_f16")
+    _lib.call("gemm_f16", a, a.stride(0), w, w.stride(0), bias, m, n, k, out, out.stride(0),
+                                       1 if out_f32 else 0, res, ld_res)
     return out
 
 
@@ -60,9 +59,8 @@ def conv3d_causal(x, w_taps, bias, T: int, H: int, W: int, cin: int, cout: int, 
     if res is not None:
         _chk(res, F16, "res")
         ld_res = res.stride(0)
-    _lib.check(_lib.load().hv_conv3d_causal_f16(_ptr(x), x.stride(0), _ptr(w_taps), _ptr(bias), _ptr(out), out.stride(0), T, H, W,
-                                                cin, cout, int(up_t), int(up_hw), _ptr(res), ld_res, _stream()),
-               "hv_conv3d_causal_f16")
+    _lib.call("conv3d_causal_f16", x, x.stride(0), w_taps, bias, out, out.stride(0), T, H, W,
+                                                cin, cout, int(up_t), int(up_hw), res, ld_res)
     return out
 
 
@@ -74,8 +72,8 @@ def conv3d_causal_strided(x, w_taps, bias, sT: int, sH: int, sW: int, cin: int, 
     st, sh, sw = (int(v) for v in stride)
     T, H, W = (sT - 1) // st + 1, (sH - 1) // sh + 1, (sW - 1) // sw + 1
     out = torch.empty(T * H * W, cout, dtype=F16, device=x.device)
-    _lib.check(_lib.load().hv_conv3d_causal_strided_f16(_ptr(x), x.stride(0), _ptr(w_taps), _ptr(bias), _ptr(out), out.stride(0),
-                                                        sT, sH, sW, cin, cout, st, sh, sw, _stream()), "hv_conv3d_causal_strided_f16")
+    _lib.call("conv3d_causal_strided_f16", x, x.stride(0), w_taps, bias, out, out.stride(0),
+                                                        sT, sH, sW, cin, cout, st, sh, sw)
     return out, T, H, W
 
 
@@ -84,8 +82,7 @@ def temporal_avg_pool(x, T: int, HW: int, k: int, s: int):
     _chk(x, F16, "x")
     t_out = (T - 1) // s + 1
     out = torch.empty(t_out * HW, x.shape[1], dtype=F16, device=x.device)
-    _lib.check(_lib.load().hv_temporal_resample_f16(_ptr(x), x.stride(0), _ptr(out), out.stride(0), T, HW, x.shape[1], 0, k, s,
-                                                    _stream()), "hv_temporal_resample_f16")
+    _lib.call("temporal_resample_f16", x, x.stride(0), out, out.stride(0), T, HW, x.shape[1], 0, k, s)
     return out, t_out
 
 
@@ -93,8 +90,7 @@ def temporal_nearest_up(x, T: int, HW: int, s: int):
     """t_ops interp: every frame repeated s times (F.interpolate nearest along T).  x [T*HW, C] -> ([T*s*HW, C], T*s)."""
     _chk(x, F16, "x")
     out = torch.empty(T * s * HW, x.shape[1], dtype=F16, device=x.device)
-    _lib.check(_lib.load().hv_temporal_resample_f16(_ptr(x), x.stride(0), _ptr(out), out.stride(0), T, HW, x.shape[1], 1, 1, s,
-                                                    _stream()), "hv_temporal_resample_f16")
+    _lib.call("temporal_resample_f16", x, x.stride(0), out, out.stride(0), T, HW, x.shape[1], 1, 1, s)
     return out, T * s
 
 
@@ -111,8 +107,8 @@ def groupnorm_affine(x, weight, bias, groups: int = 32, eps: float = 1e-6):
         ws = torch.empty(1024 * c * 2, dtype=torch.float32, device=x.device)
         _gn_ws[key] = ws
     aff = torch.empty(c, 2, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().hv_groupnorm_affine_f16(_ptr(x), x.stride(0), m, c, groups, eps, _ptr(weight), _ptr(bias), _ptr(ws),
-                                                   ws.numel(), _ptr(aff), _stream()), "hv_groupnorm_affine_f16")
+    _lib.call("groupnorm_affine_f16", x, x.stride(0), m, c, groups, eps, weight, bias, ws,
+                                                   ws.numel(), aff)
     return aff
 
 
@@ -121,8 +117,7 @@ def groupnorm_apply(x, affine, silu: bool, out=None):
     m, c = x.shape
     if out is None:
         out = torch.empty(m, c, dtype=F16, device=x.device)
-    _lib.check(_lib.load().hv_groupnorm_apply_f16(_ptr(x), x.stride(0), _ptr(out), out.stride(0), m, c, _ptr(affine), int(silu),
-                                                  _stream()), "hv_groupnorm_apply_f16")
+    _lib.call("groupnorm_apply_f16", x, x.stride(0), out, out.stride(0), m, c, affine, int(silu))
     return out
 
 
@@ -131,8 +126,8 @@ def softmax_rows(s_f32, cols: int, cols_pad: int, scale: float, out=None):
     rows = s_f32.shape[0]
     if out is None:
         out = torch.empty(rows, cols_pad, dtype=F16, device=s_f32.device)
-    _lib.check(_lib.load().hv_softmax_rows_f32_f16(_ptr(s_f32), s_f32.stride(0), _ptr(out), out.stride(0), rows, cols, cols_pad,
-                                                   scale, _stream()), "hv_softmax_rows_f32_f16")
+    _lib.call("softmax_rows_f32_f16", s_f32, s_f32.stride(0), out, out.stride(0), rows, cols, cols_pad,
+                                                   scale)
     return out
 
 
@@ -140,7 +135,7 @@ def transpose_16b(src, dst):
     """dst[c, r] = src[r, c] for 2-D 16-bit views."""
     assert src.element_size() == 2 and dst.element_size() == 2 and src.is_cuda and dst.is_cuda
     r, c = src.shape
-    _lib.check(_lib.load().hv_transpose_16b(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), r, c, _stream()), "hv_transpose_16b")
+    _lib.call("transpose_16b", src, src.stride(0), dst, dst.stride(0), r, c)
     return dst
 
 
@@ -150,8 +145,7 @@ def latent_tile(z_f32_view, cpad: int):
     c, t, h, w = z_f32_view.shape
     sc, st, sh, sw = z_f32_view.stride()
     out = torch.empty(t * h * w, cpad, dtype=F16, device=z_f32_view.device)
-    _lib.check(_lib.load().hv_vae_latent_tile_f16(_ptr(z_f32_view), sc, st, sh, sw, c, t, h, w, cpad, _ptr(out), _stream()),
-               "hv_vae_latent_tile_f16")
+    _lib.call("vae_latent_tile_f16", z_f32_view, sc, st, sh, sw, c, t, h, w, cpad, out)
     return out
 
 
@@ -161,8 +155,8 @@ def blend_(a_view, b_view, axis: int, extent: int):
     assert a_view.shape == b_view.shape and a_view.dim() == 4
     if b_view.numel() == 0:
         return b_view          # empty overlap (e.g. a trailing temporal tile of a single latent frame): nothing to blend
-    _lib.check(_lib.load().hv_vae_blend_f16(_ptr(a_view), _i64x4(a_view.stride()), _ptr(b_view), _i64x4(b_view.stride()),
-                                            _i32x4(b_view.shape), axis, extent, _stream()), "hv_vae_blend_f16")
+    _lib.call("vae_blend_f16", a_view, _i64x4(a_view.stride()), b_view, _i64x4(b_view.stride()),
+                                            _i32x4(b_view.shape), axis, extent)
     return b_view
 
 
@@ -171,8 +165,8 @@ def copy4d_(src_view, dst_view):
     assert src_view.is_cuda and dst_view.is_cuda
     if dst_view.numel() == 0:
         return dst_view
-    _lib.check(_lib.load().hv_copy4d_16b(_ptr(src_view), _i64x4(src_view.stride()), _ptr(dst_view), _i64x4(dst_view.stride()),
-                                         _i32x4(dst_view.shape), _stream()), "hv_copy4d_16b")
+    _lib.call("copy4d_16b", src_view, _i64x4(src_view.stride()), dst_view, _i64x4(dst_view.stride()),
+                                         _i32x4(dst_view.shape))
     return dst_view
 
 
@@ -180,5 +174,5 @@ def postprocess(x_f16):
     _chk(x_f16, F16, "x")
     assert x_f16.is_contiguous()
     out = torch.empty(x_f16.shape, dtype=torch.float32, device=x_f16.device)
-    _lib.check(_lib.load().hv_vae_postprocess_f16_f32(_ptr(x_f16), _ptr(out), x_f16.numel(), _stream()), "hv_vae_postprocess_f16_f32")
+    _lib.call("vae_postprocess_f16_f32", x_f16, out, x_f16.numel())
     return out

@@ -107,6 +107,9 @@ int hv_unpatchify_bf16(const void* y, void* out, int C, int T, int H, int W, int
  * sample_f32[i] += f32(model_out_bf16[i]) * dt. */
 int hv_euler_step_f32(float* sample, const void* model_out_bf16, float dt, int64_t n, hipStream_t stream);
 
+/* K13 with an fp32 velocity (the reference upcasts model_output, :239): sample_f32[i] += model_out_f32[i] * dt. */
+int hv_euler_step_f32_f32(float* sample, const float* model_out_f32, float dt, int64_t n, hipStream_t stream);
+
 /* token_refiner.py:222-228: out[d] = sum_l x[l][d]*mask[l] / sum_l mask[l]  (mask NULL = plain mean). */
 int hv_masked_mean_bf16(const void* x, const int* mask, void* out, int L, int D, hipStream_t stream);
 

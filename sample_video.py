@@ -20,7 +20,8 @@ def parse_args():
     p.add_argument("--vae-precision", default="fp16", choices=["fp16"])
     p.add_argument("--vae-tiling", action="store_true", default=True)
     p.add_argument("--flow-shift", type=float, default=7.0)
-    p.add_argument("--flow-reverse", action="store_true", default=True)
+    p.add_argument("--flow-reverse", action="store_true", help="If reverse, learning/sampling from t=1 -> t=0 (config.py:193-196; the "
+                   "reference's launch scripts always pass it)")
     p.add_argument("--flow-solver", default="euler")
     p.add_argument("--infer-steps", type=int, default=50)
     p.add_argument("--video-size", type=int, nargs="+", default=[720, 1280])
@@ -57,7 +58,7 @@ def main():
     a = parse_args()
     from hunyuanvideo_efficiency_amd import synthetic as syn
     from hunyuanvideo_efficiency_amd.inference import init_distributed, parallelize_transformer, get_rotary_pos_embed
-    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.builders import build_model
     from hunyuanvideo_efficiency_amd.vae import AutoencoderKLCausal3D
     from hunyuanvideo_efficiency_amd.diffusion.schedulers import FlowMatchDiscreteScheduler
     from hunyuanvideo_efficiency_amd.diffusion.pipelines import HunyuanVideoPipeline
@@ -70,10 +71,13 @@ def main():
     cfg = syn.tiny_config() if a.tiny else syn.DiTConfig()
     model = build_model(cfg, dev, seed=0)
     if a.dit_weight or a.model_base:
-        # real weights: same order as the reference (inference.py:199-202): fp8 conversion (scales from <ckpt>_map.pt), then load
+        # real weights: same order as the reference (inference.py:199-202): fp8 conversion (scales from <ckpt>_map.pt), then load.
+        # The checkpoint path is resolved FIRST so that convert_fp8_linear reads the map that belongs to the weights being loaded
+        # (quantising the random-init weights with their own scales and then copying real fp8 weights over them would be wrong).
         from hunyuanvideo_efficiency_amd import checkpoint
+        ckpt = checkpoint.resolve_dit_path(a, a.model_base)
         if a.use_fp8:
-            convert_fp8_linear(model, a.dit_weight, torch.bfloat16)
+            convert_fp8_linear(model, str(ckpt), torch.bfloat16)
         checkpoint.load_state_dict(a, model, a.model_base)
     elif a.use_fp8:
         convert_fp8_linear(model, None, torch.bfloat16)
@@ -102,7 +106,7 @@ def main():
             text_encoder_2 = TextEncoder("clipL", a.text_len_2, a.text_encoder_precision, a.text_encoder_2_path, tokenizer_type="clipL",
                                          device=dev)
     pipe = HunyuanVideoPipeline(vae, model, sched, a, text_encoder=text_encoder, text_encoder_2=text_encoder_2)
-    if a.ulysses_degree > 1:
+    if a.ulysses_degree > 1 or a.ring_degree > 1:      # inference.py:157,408
         parallelize_transformer(pipe)
     lt = (a.video_length - 1) // 4 + 1
     _, ts, tm, ts2 = syn.synth_dit_inputs(cfg, (lt, h // 8, w // 8), a.text_len, 11, seed=a.seed, device=dev)

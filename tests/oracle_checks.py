@@ -1,38 +1,17 @@
-"""One tiny denoise step on the GPU checked against the oracle - used by __graft_entry__.smoke() and the GPU tests.
-(Imports oracle/ as the CHECKER only.)"""
+"""Checker: one tiny denoise step on the GPU against the oracle - used by __graft_entry__.smoke() and tests/test_gpu_model.py.
+Test infrastructure (this file lives under tests/ because it imports oracle/; the package itself never does)."""
 from __future__ import annotations
-
-import types
 
 import torch
 
-from . import synthetic as syn
-
-
-def build_model(cfg: syn.DiTConfig, device, seed: int = 0):
-    from .modules.models import HYVideoDiffusionTransformer
-    args = types.SimpleNamespace(text_states_dim=cfg.text_states_dim, text_states_dim_2=cfg.text_states_dim_2)
-    with torch.device("meta"):
-        model = HYVideoDiffusionTransformer(
-            args, in_channels=cfg.in_channels, out_channels=cfg.out_channels, hidden_size=cfg.hidden_size,
-            heads_num=cfg.heads_num, mlp_width_ratio=cfg.mlp_width_ratio,
-            mm_double_blocks_depth=cfg.mm_double_blocks_depth, mm_single_blocks_depth=cfg.mm_single_blocks_depth,
-            rope_dim_list=cfg.rope_dim_list, guidance_embed=cfg.guidance_embed, dtype=torch.bfloat16)
-    model.to_empty(device=device)
-    shapes = syn.dit_param_shapes(cfg)
-    sd = model.state_dict()
-    assert set(sd) == set(shapes), set(sd) ^ set(shapes)
-    with torch.no_grad():
-        for k, p in sd.items():
-            assert tuple(p.shape) == tuple(shapes[k]), (k, p.shape, shapes[k])
-            p.copy_(syn.synth_param(k, shapes[k], seed, device).to(p.dtype))
-    return model.eval()
+from hunyuanvideo_efficiency_amd import synthetic as syn
+from hunyuanvideo_efficiency_amd.builders import build_model
 
 
 def tiny_step_vs_oracle(device="cuda:0", latent_thw=(5, 16, 16), txt_len=32, n_valid=11) -> float:
     from oracle import dit_ref as R
-    from .diffusion.schedulers import FlowMatchDiscreteScheduler
-    from .modules.posemb_layers import get_nd_rotary_pos_embed
+    from hunyuanvideo_efficiency_amd.diffusion.schedulers import FlowMatchDiscreteScheduler
+    from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
     cfg = syn.tiny_config()
     model = build_model(cfg, device)
     x, ts, tm, ts2 = syn.synth_dit_inputs(cfg, latent_thw, txt_len, n_valid, seed=0)

@@ -43,3 +43,27 @@ def test_ops_refuse_cpu_tensors():
         ops.ln_modulate(torch.zeros(4, 256, dtype=torch.bfloat16))
     with pytest.raises(_lib.HVKernelError):
         ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16))
+
+
+def test_torch_custom_ops_registered_for_every_entry_point():
+    """SURVEY.md 8b last row: every C-ABI entry point is a PyTorch custom op torch.ops.hv.<name> (TORCH_LIBRARY(hv, m)); the
+    kernels are registered for the CUDA(=HIP) dispatch key only - a CPU tensor is refused by the dispatcher (no CPU path)."""
+    import torch
+    from hunyuanvideo_efficiency_amd import _lib
+    hv = _lib.torch_ops()
+    for name in _header_decls():
+        op = getattr(hv, name[len("hv_"):])
+        assert op.default._schema.name == "hv::" + name[len("hv_"):]
+    assert int(hv.abi_version()) == _lib.ABI_VERSION
+    assert _lib.host("attn_suggest_splits", 118811, 118811, 3) == 2        # Ulysses-8 shape: shallow grid -> KV split
+    assert _lib.host("attn_suggest_splits", 118811, 118811, 24) == 1
+    with pytest.raises(_lib.HVKernelError):
+        _lib.call("euler_step_f32", torch.zeros(4), torch.zeros(4, dtype=torch.bfloat16), 0.1, 4)
+
+
+def test_generated_torch_ops_source_is_up_to_date():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_torch_ops", os.path.join(ROOT, "tools", "gen_torch_ops.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    assert open(g.OUT).read() == g.gen(), "include/hv_kernels.h changed: run python tools/gen_torch_ops.py"

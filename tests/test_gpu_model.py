@@ -20,13 +20,13 @@ def rel(a, b):
 
 @pytest.fixture(scope="module")
 def tiny():
-    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.builders import build_model
     cfg = syn.tiny_config()
     return cfg, build_model(cfg, DEV)
 
 
 def test_tiny_step_vs_oracle():
-    from hunyuanvideo_efficiency_amd.selftest import tiny_step_vs_oracle
+    from tests.oracle_checks import tiny_step_vs_oracle
     assert tiny_step_vs_oracle(DEV) < 3e-2
 
 
@@ -114,7 +114,7 @@ def test_sequence_parallel_path_single_rank_rccl(tiny, golden):
     import os
     import torch.distributed as dist
     from hunyuanvideo_efficiency_amd.inference import parallelize_transformer_module
-    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.builders import build_model
     from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
     cfg, model = tiny
     g = golden("dit_tiny_forward")
@@ -146,7 +146,7 @@ def test_fp8_weight_path(tiny, golden):
     weights == oracle forward with the dequantised bf16 weights (the reference's semantics: weight-only FP8)."""
     from hunyuanvideo_efficiency_amd import ops
     from hunyuanvideo_efficiency_amd.modules.fp8_optimization import convert_fp8_linear
-    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.builders import build_model
     from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
     codes = torch.arange(256, dtype=torch.uint8).repeat(4).to(DEV).view(torch.float8_e4m3fn)
     scale = torch.tensor([0.01171875], dtype=torch.bfloat16, device=DEV)

@@ -19,7 +19,7 @@ DEV = "cuda:0"
 
 
 def test_pipeline_denoise_and_decode_vs_oracle():
-    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.builders import build_model
     from hunyuanvideo_efficiency_amd.vae import AutoencoderKLCausal3D
     from hunyuanvideo_efficiency_amd.diffusion.schedulers import FlowMatchDiscreteScheduler
     from hunyuanvideo_efficiency_amd.diffusion.pipelines import HunyuanVideoPipeline
@@ -86,7 +86,7 @@ def test_pipeline_prompt_surface_with_text_encoders():
     from tests.test_text_encoder_cpu import _llm, _toy_tokenizer
     from transformers import CLIPTextConfig, CLIPTextModel
     from hunyuanvideo_efficiency_amd.text_encoder import TextEncoder
-    from hunyuanvideo_efficiency_amd.selftest import build_model
+    from hunyuanvideo_efficiency_amd.builders import build_model
     from hunyuanvideo_efficiency_amd.vae import AutoencoderKLCausal3D
     from hunyuanvideo_efficiency_amd.diffusion.schedulers import FlowMatchDiscreteScheduler
     from hunyuanvideo_efficiency_amd.diffusion.pipelines import HunyuanVideoPipeline

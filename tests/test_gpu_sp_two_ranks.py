@@ -97,7 +97,7 @@ def _worker(rank, world, port, outdir):
     try:
         torch.cuda.set_device(0)
         _stage_collectives_through_host()
-        from hunyuanvideo_efficiency_amd import selftest, synthetic as syn
+        from hunyuanvideo_efficiency_amd import builders as selftest, synthetic as syn
         from hunyuanvideo_efficiency_amd.inference import parallelize_transformer_module
         from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
         cfg = syn.DiTConfig(hidden_size=512, heads_num=4, mm_double_blocks_depth=1, mm_single_blocks_depth=2)
@@ -184,7 +184,7 @@ def _ring_worker(rank, world, port, outdir, U, R):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0")
     try:
         torch.cuda.set_device(0)
-        from hunyuanvideo_efficiency_amd import selftest, synthetic as syn
+        from hunyuanvideo_efficiency_amd import builders as selftest, synthetic as syn
         from hunyuanvideo_efficiency_amd.inference import init_distributed, parallelize_transformer_module
         from hunyuanvideo_efficiency_amd.modules.posemb_layers import get_nd_rotary_pos_embed
         init_distributed(U, R, backend="gloo")
