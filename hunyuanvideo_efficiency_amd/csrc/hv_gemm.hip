@@ -21,8 +21,16 @@
 // Algorithmic work: 2*M*N*K flop; HBM bytes >= 2*(M*K + N*K + M*N).
 #include "hv_common.hpp"
 #include "../../include/hv_kernels.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
+
+// HV_GEMM_2STAGE=1 in the environment keeps every plain GEMM on the 2-stage main loop (same-box A/B of the two loops)
+inline bool hv_gemm_force_2stage() {
+    static const bool v = [] { const char* e = std::getenv("HV_GEMM_2STAGE"); return e && e[0] == '1'; }();
+    return v;
+}
 
 constexpr int BM = 256, BK = 64;                 // BN is a template parameter: 256 (default) or 128 (N <= 128: VAE 128-channel convs)
 constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB per A tile (W tile: BN * BK * 2)
@@ -78,6 +86,71 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return gelu_tanh_f(v);
     if (act == 2) return silu_f(v);
     return v;
+}
+
+// ---- epilogue shared by both main loops: lane holds, per (mi, n-repeat pair), 8 consecutive n of row m
+template <typename DT, int BN, int NREP>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[8][NREP], int m0, int n0, int wm, int wn, int fr, int fq) {
+    auto unpack = [](const u32x4& w, float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = DT::lo(w[i]);
+            f[2 * i + 1] = DT::hi(w[i]);
+        }
+    };
+    const int mrow0 = m0 + wm * 128 + fr;
+#pragma unroll
+    for (int np = 0; np < NREP / 2; ++np) {
+        const int n = n0 + wn * (BN / 4) + np * 32 + fq * 8;
+        if (n >= g.N) continue;
+        float b[8], gt[8];
+        if (g.bias) unpack(*reinterpret_cast<const u32x4*>(g.bias + n), b);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = 0.f;
+        }
+        if (g.gate) unpack(*reinterpret_cast<const u32x4*>(g.gate + n), gt);
+        const bool second = n >= g.n_split;
+        uint16_t* obase = second ? g.out1 + (n - g.n_split) : g.out0 + n;
+        const int64_t ldo = second ? g.ld1 : g.ld0;
+        const int act = second ? g.act1 : g.act0;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = mrow0 + mi * 16;
+            if (m >= g.M) continue;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[mi][2 * np][r] + b[r];
+                v[4 + r] = acc[mi][2 * np + 1][r] + b[4 + r];
+            }
+            if (g.out_f32) {
+                float4* o = reinterpret_cast<float4*>(g.out_f32 + (int64_t)m * g.ld0 + n);
+                o[0] = make_float4(v[0], v[1], v[2], v[3]);
+                o[1] = make_float4(v[4], v[5], v[6], v[7]);
+                continue;
+            }
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = apply_act(DT::round(v[j]), act);
+            }
+            if (g.res) {
+                float rs[8];
+                unpack(*reinterpret_cast<const u32x4*>(g.res + (int64_t)m * g.ld_res + n), rs);
+                if (g.gate) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = rs[j] + DT::round(DT::round(v[j]) * gt[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = rs[j] + DT::round(v[j]);
+                }
+            }
+            u32x4 w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = DT::pack(v[2 * i], v[2 * i + 1]);
+            *reinterpret_cast<u32x4*>(obase + (int64_t)m * ldo) = w;
+        }
+    }
 }
 
 template <typename DT, bool CONV, int BN>
@@ -245,67 +318,217 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds, per (mi, n-repeat pair), 8 consecutive n of row m
-    auto unpack = [](const u32x4& w, float (&f)[8]) {
+    gemm_epilogue<DT, BN, NREP>(g, acc, m0, n0, wm, wn, fr, fq);
+}
+
+// =====================================================================================================================
+// Plain GEMM, N > 128, K >= 192: the pipelined main loop ("8 phases": two K-tiles x four 16-MFMA phases per iteration).
+//
+// Why: the 2-stage loop above issues a whole K-tile's DMA, 24 fragment reads and 64 MFMAs per wave between two
+// __syncthreads(), each of which drains the LDS-DMA queue (vmcnt(0)): the matrix pipe idles while every wave of the CU reads
+// its fragments at once, and again while the next tile's DMA lands (36 % SQ_WAIT_ANY, 43-44 % of the MFMA roof).  Here
+//   * a K-tile is cut into four 16 KiB half-tiles in the order they are consumed - Am0 (rows wm*128 + [0,64) of both wave
+//     rows), Bn0 (W rows wn*64 + [0,32) of all four wave columns), Bn1, Am1 - and a phase computes one 64 x 32 output
+//     quadrant per wave (4 x 2 accumulators x 2 k-steps = 16 MFMAs): Q(m0,n0), Q(m0,n1), Q(m1,n1), Q(m1,n0); the fragments
+//     it needs beyond what is already in registers are ONE half-tile's (12 / 4 / 8 / 0 ds_read_b128);
+//   * every phase issues one half-tile of LDS-DMA (2 global_load_lds_dwordx4 per thread) for the K-tile TWO ahead into the
+//     slot whose last reader finished the phase before, and waits with a COUNTED vmcnt(10): five half-tiles (80 KiB per CU)
+//     stay in flight across the raw s_barriers, the DMA queue is never drained inside the loop;
+//   * the two wave rows (waves 0-3 / 4-7 = the two waves of every SIMD) run the same program one barrier apart, so in every
+//     barrier interval one of them is in its MFMA cluster and the other in its fragment reads + DMA issue: the matrix pipe
+//     of each SIMD is fed back to back, and at most four waves read LDS at a time.
+// Hazards (guide: "Read a staged buffer one phase AFTER the wait that retires it"; WAR: a slot is re-staged only after a barrier
+// that follows its readers' lgkmcnt(0)): with phase index f = 4*tile + p, phase f reads half-tiles <= f+1 and issues half-tile
+// f+7; each wave waits, before the barrier that ends its read segment, for its own share of half-tile f+2 (vmcnt(10)) and for
+// its fragment reads (lgkmcnt(0)).  Both wave rows pass a barrier between any wait and the first read that depends on it, and
+// between the last read of a slot and the DMA that overwrites it (slot of Am0/Bn0: free after phase 1, re-staged in phases
+// 2/3; Bn1: after 2, in 4; Am1: after 3, in the next tile's phase 1).
+constexpr int HT_BYTES = 16384;            // half-tile: 128 rows x 64 k x 2 B
+constexpr int BUF8_BYTES = 4 * HT_BYTES;   // [Am0 | Bn0 | Bn1 | Am1] of one K-tile
+constexpr int LDS8_BYTES = 2 * BUF8_BYTES; // 128 KiB
+
+template <typename DT>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
+    typedef typename DT::vec8 vec8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nwg = gridDim.x;
+    int lin;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int band = lin / (GROUP_M * g.tiles_n), rem = lin % (GROUP_M * g.tiles_n);
+    const int band_m0 = band * GROUP_M;
+    const int gm = min(GROUP_M, g.tiles_m - band_m0);
+    const int tm = band_m0 + rem % gm, tn = rem / gm;
+    const int m0 = tm * BM, n0 = tn * 256;
+
+    // ---- staging: thread -> (row srow of a 64-row piece, 16-B chunk position scp); 2 pieces per half-tile
+    const int srow = tid >> 3, scp = tid & 7;
+    uint32_t a_o[2][2], w_o[2][2];      // [half][piece] invariant per-lane byte offsets from the scalar K-tile base
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f[2 * i] = DT::lo(w[i]);
-            f[2 * i + 1] = DT::hi(w[i]);
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int arow = i * 128 + h * 64 + srow;                       // tile row of LDS row (i*64 + srow) of half-tile Am<h>
+            a_o[h][i] = (uint32_t)(((int64_t)(min(m0 + arow, g.M - 1) - m0) * g.lda + ((scp ^ swz_a(srow)) << 3)) * 2);
+            const int lr = i * 64 + srow;                                   // LDS row of half-tile Bn<h>
+            const int wrow = (lr >> 5) * 64 + h * 32 + (lr & 31);           // wave column (lr>>5), its W rows [h*32, h*32+32)
+            w_o[h][i] = (uint32_t)(((int64_t)(min(n0 + wrow, g.N - 1) - n0) * g.ldw + ((scp ^ swz_w(lr)) << 3)) * 2);
+        }
+    const int wave_lds = wave * 1024;
+    const char* a_tile = reinterpret_cast<const char*>(g.A + (int64_t)m0 * g.lda);
+    const char* w_tile = reinterpret_cast<const char*>(g.W + (int64_t)n0 * g.ldw);
+
+    // half-tile J (0 Am0, 1 Bn0, 2 Bn1, 3 Am1) of K-tile `tile` into buffer `buf` (wave-uniform: the destination goes through M0)
+    auto stage = [&](auto Jc, int buf, int tile) {
+        constexpr int J = decltype(Jc)::value;
+        char* dst = smem + buf * BUF8_BYTES + J * HT_BYTES + wave_lds;
+        constexpr bool isA = (J == 0 || J == 3);
+        constexpr int h = (J == 3 || J == 2) ? 1 : 0;
+        uint64_t bv = reinterpret_cast<uint64_t>((isA ? a_tile : w_tile) + (int64_t)tile * (BK * 2));
+        asm volatile("" : "+s"(bv));
+        const char* b = reinterpret_cast<const char*>(bv);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint32_t o = isA ? a_o[h][i] : w_o[h][i];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b + o), (lds_ptr_t)(dst + i * 8192), 16, 0, 0);
         }
     };
-    const int mrow0 = m0 + wm * 128 + fr;
+
+    // ---- fragment read offsets inside a half-tile (k-step 0; k-step 1 flips chunk bit 2 = byte bit 6)
+    const int fr = lane & 15, fq = lane >> 4;
+    const int a_rd = (wm * 64 + fr) * 128 + ((fq ^ swz_a(fr)) << 4);                         // + mi * 2048
+    const int w_lr = wn * 32 + (fr >> 2) * 8 + (fr & 3);                                     // + (ni & 1) * 4 rows = 512 B
+    const int w_rd = w_lr * 128 + ((fq ^ swz_w(w_lr)) << 4);
+
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int np = 0; np < NREP / 2; ++np) {
-        const int n = n0 + wn * (BN / 4) + np * 32 + fq * 8;
-        if (n >= g.N) continue;
-        float b[8], gt[8];
-        if (g.bias) unpack(*reinterpret_cast<const u32x4*>(g.bias + n), b);
-        else {
+    for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = 0.f;
-        }
-        if (g.gate) unpack(*reinterpret_cast<const u32x4*>(g.gate + n), gt);
-        const bool second = n >= g.n_split;
-        uint16_t* obase = second ? g.out1 + (n - g.n_split) : g.out0 + n;
-        const int64_t ldo = second ? g.ld1 : g.ld0;
-        const int act = second ? g.act1 : g.act0;
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    vec8 af[4][2], wf0[2][2], wf1[2][2];
+
+    auto readA = [&](auto BUFc, auto MHc) {
+        constexpr int BUF = decltype(BUFc)::value, MH = decltype(MHc)::value;
+        const char* base = smem + BUF * BUF8_BYTES + (MH ? 3 : 0) * HT_BYTES;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = mrow0 + mi * 16;
-            if (m >= g.M) continue;
-            float v[8];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[mi][2 * np][r] + b[r];
-                v[4 + r] = acc[mi][2 * np + 1][r] + b[4 + r];
-            }
-            if (g.out_f32) {
-                float4* o = reinterpret_cast<float4*>(g.out_f32 + (int64_t)m * g.ld0 + n);
-                o[0] = make_float4(v[0], v[1], v[2], v[3]);
-                o[1] = make_float4(v[4], v[5], v[6], v[7]);
-                continue;
-            }
-            if (act) {
+            for (int mi = 0; mi < 4; ++mi) af[mi][ks] = *reinterpret_cast<const vec8*>(base + ((a_rd ^ (ks << 6)) + mi * 2048));
+    };
+    auto readB = [&](auto BUFc, auto NHc, vec8 (&wf)[2][2]) {
+        constexpr int BUF = decltype(BUFc)::value, NH = decltype(NHc)::value;
+        const char* base = smem + BUF * BUF8_BYTES + (1 + NH) * HT_BYTES;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = apply_act(DT::round(v[j]), act);
-            }
-            if (g.res) {
-                float rs[8];
-                unpack(*reinterpret_cast<const u32x4*>(g.res + (int64_t)m * g.ld_res + n), rs);
-                if (g.gate) {
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = rs[j] + DT::round(DT::round(v[j]) * gt[j]);
-                } else {
+            for (int nl = 0; nl < 2; ++nl) wf[nl][ks] = *reinterpret_cast<const vec8*>(base + ((w_rd ^ (ks << 6)) + nl * 512));
+    };
+    auto mma = [&](auto MHc, auto NHc, const vec8 (&wf)[2][2]) {
+        constexpr int MH = decltype(MHc)::value, NH = decltype(NHc)::value;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = rs[j] + DT::round(v[j]);
-                }
-            }
-            u32x4 w;
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = DT::pack(v[2 * i], v[2 * i + 1]);
-            *reinterpret_cast<u32x4*>(obase + (int64_t)m * ldo) = w;
-        }
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl)
+                    acc[MH * 4 + mi][NH * 2 + nl] = DT::mfma(wf[nl][ks], af[mi][ks], acc[MH * 4 + mi][NH * 2 + nl]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // one phase: [fragment reads | DMA issue | counted waits] barrier [16 MFMAs] barrier.   VM = vmcnt literal of this phase.
+#define HV_PHASE_SYNC(VM)                                            \
+    asm volatile("s_waitcnt vmcnt(" #VM ")\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_barrier();                                     \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_setprio(1);
+#define HV_PHASE_END()                                                \
+    __builtin_amdgcn_s_setprio(0);                                    \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_barrier();                                     \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // KIND 0: steady (every phase issues, vmcnt(10)); 1: tile nkt-2 (only phase 1 issues; 10, 8, 6, 4); 2: tile nkt-1 (2, 0, 0, 0)
+    auto tile_fn = [&](auto BUFc, auto KINDc, int t) {
+        constexpr int BUF = decltype(BUFc)::value, KIND = decltype(KINDc)::value;
+        using B = std::integral_constant<int, BUF>;
+        // phase 1: Q(m0, n0)
+        readB(B{}, I0{}, wf0);
+        __builtin_amdgcn_sched_barrier(0);
+        readA(B{}, I0{});
+        if constexpr (KIND <= 1) stage(I3{}, BUF ^ 1, t + 1);
+        if constexpr (KIND <= 1) { HV_PHASE_SYNC(10) } else { HV_PHASE_SYNC(2) }
+        mma(I0{}, I0{}, wf0);
+        HV_PHASE_END()
+        // phase 2: Q(m0, n1)
+        readB(B{}, I1{}, wf1);
+        if constexpr (KIND == 0) stage(I0{}, BUF, t + 2);
+        if constexpr (KIND == 0) { HV_PHASE_SYNC(10) } else if constexpr (KIND == 1) { HV_PHASE_SYNC(8) } else { HV_PHASE_SYNC(0) }
+        mma(I0{}, I1{}, wf1);
+        HV_PHASE_END()
+        // phase 3: Q(m1, n1)
+        readA(B{}, I1{});
+        if constexpr (KIND == 0) stage(I1{}, BUF, t + 2);
+        if constexpr (KIND == 0) { HV_PHASE_SYNC(10) } else if constexpr (KIND == 1) { HV_PHASE_SYNC(6) } else { HV_PHASE_SYNC(0) }
+        mma(I1{}, I1{}, wf1);
+        HV_PHASE_END()
+        // phase 4: Q(m1, n0)   (B(n0) still in registers from phase 1)
+        if constexpr (KIND == 0) stage(I2{}, BUF, t + 2);
+        if constexpr (KIND == 0) { HV_PHASE_SYNC(10) } else if constexpr (KIND == 1) { HV_PHASE_SYNC(4) } else { HV_PHASE_SYNC(0) }
+        mma(I1{}, I0{}, wf0);
+        HV_PHASE_END()
+    };
+
+    // ---- prologue: half-tiles 0..6 (K-tile 0 and Am0, Bn0, Bn1 of K-tile 1); phase 0 reads half-tiles 0 and 1.
+    // K-tile t lives in buffer (t + par) & 1 with par = (number of steady tiles) & 1, so that the unrolled pair loop and the two
+    // tail tiles always see buffers (0, 1): an odd steady count is absorbed by ONE peeled tile in front, not by a second copy of the tail.
+    const int nkt = g.K / BK;      // >= 3 (host-side dispatch)
+    const int ns = nkt - 2;        // steady tiles 0 .. nkt-3
+    const int par = ns & 1;
+    stage(I0{}, par, 0); stage(I1{}, par, 0); stage(I2{}, par, 0); stage(I3{}, par, 0);
+    stage(I0{}, par ^ 1, 1); stage(I1{}, par ^ 1, 1); stage(I2{}, par ^ 1, 1);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();      // the second wave row runs one barrier interval behind the first
+    __builtin_amdgcn_sched_barrier(0);
+
+    int t = 0;
+    if (par) {
+        tile_fn(I1{}, I0{}, 0);
+        t = 1;
     }
+    for (; t < ns; t += 2) {
+        tile_fn(I0{}, I0{}, t);
+        tile_fn(I1{}, I0{}, t + 1);
+    }
+    tile_fn(I0{}, I1{}, t);
+    tile_fn(I1{}, I2{}, t + 1);
+    if (wm == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count of the staggered rows
+#undef HV_PHASE_SYNC
+#undef HV_PHASE_END
+    gemm_epilogue<DT, 256, 4>(g, acc, m0, n0, wm, wn, fr, fq);
+}
+
+template <typename DT>
+int launch_gemm8(GemmArgs& g, hipStream_t stream) {
+    static HvPerDeviceOnce once;
+    if (hv_set_max_lds(once, (const void*)gemm8_kernel<DT>, LDS8_BYTES) != HV_OK) return HV_ERR_LAUNCH;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + 255) / 256;
+    gemm8_kernel<DT><<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS8_BYTES, stream>>>(g);
+    return hv_check_launch();
 }
 
 template <typename DT, bool CONV, int BN>
@@ -322,7 +545,11 @@ template <typename DT, bool CONV>
 int launch(GemmArgs& g, hipStream_t stream) {
     // narrow outputs (N <= 128: the VAE's 128-channel and output convs, small projections) take the 256x128 tile so that at
     // most half a tile of MFMA work is padding
-    return g.N <= 128 ? launch_bn<DT, CONV, 128>(g, stream) : launch_bn<DT, CONV, 256>(g, stream);
+    if (g.N <= 128) return launch_bn<DT, CONV, 128>(g, stream);
+    if constexpr (!CONV) {
+        if (g.K >= 3 * BK && !hv_gemm_force_2stage()) return launch_gemm8<DT>(g, stream);     // pipelined main loop
+    }
+    return launch_bn<DT, CONV, 256>(g, stream);
 }
 
 int fill_common(GemmArgs& g, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, int M, int N, int K,

@@ -206,8 +206,8 @@ def test_groupnorm_production_shape():
     var = (s2.reshape(32, -1).sum(1) / n_el).cpu() - mean ** 2
     rstd = (var + 1e-6).rsqrt()
     rows = _sample_rows(M, 200, "gn.rows").to(DEV)
-    xn = (x[rows].float().reshape(-1, 32, C // 32).double() - mean[None, :, None]) * rstd[None, :, None]
-    ref = torch.nn.functional.silu(xn.reshape(-1, C).float() * w.float() + b.float())
+    xn = (x[rows].float().cpu().reshape(-1, 32, C // 32).double() - mean[None, :, None]) * rstd[None, :, None]
+    ref = torch.nn.functional.silu(xn.reshape(-1, C).float() * w.float().cpu() + b.float().cpu())
     torch.testing.assert_close(y[rows].float().cpu(), ref.cpu(), rtol=2 ** -9, atol=3e-3)
 
 

@@ -54,11 +54,14 @@ def test_pipeline_denoise_and_decode_vs_oracle():
     # prompt embeddings arrive in fp16 (prompt_embeds.dtype) exactly as the pipeline passes them
     lat, _ = RD.denoise_loop(sd, cfg, x0.clone(), n_steps, ts.to(torch.float16).float(), tm, ts2.to(torch.float16).float(),
                              cos, sin, 6.0, 7.0, E)
-    # the GPU latents after the loop, via the output_type="latent" surface
+    # the GPU latents after the loop, via the output_type="latent" surface - which, like the reference
+    # (pipeline_hunyuan_video.py:1088-1092), returns them post-scaled: (x / 2 + 0.5).clamp(0, 1)
     lat_gpu = pipe(ts.to(torch.float16).to(DEV), tm.to(DEV), ts2.to(torch.float16).to(DEV), height, width, frames,
                    num_inference_steps=n_steps, embedded_guidance_scale=6.0, latents=x0.clone(), freqs_cis=freqs,
                    output_type="latent", n_tokens=freqs[0].shape[0]).videos
-    err_lat = float((lat_gpu - lat).abs().max() / lat.abs().max())
+    lat_post = (lat / 2 + 0.5).clamp(0, 1)
+    assert float(lat_post.min()) == 0.0 and float(lat_post.max()) == 1.0 and 0.2 < float(((lat_post > 0) & (lat_post < 1)).float().mean())
+    err_lat = float((lat_gpu - lat_post).abs().max())
     assert err_lat < 2e-2, err_lat
 
     EV = RV.Prec(True)
