@@ -21,6 +21,7 @@
 #include "hv_common.hpp"
 #include "../../include/hv_kernels.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -306,6 +307,285 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v2(AttnArgs a) {
 }
 
 
+// =====================================================================================================================
+// v3 = v2 with the softmax's scale/subtract pass moved into the matrix pipe and the row max moved under the P.V MFMAs:
+//   * Q is pre-multiplied by scale*log2(e) once (bf16), so S = K.Q'^T is already in the exp2 domain;
+//   * the running max is DEFERRED (threshold 2^8) and enters as the C operand of each S chain (16 registers holding -m), so
+//     P = exp2(S') needs no VALU work besides the exp itself;
+//   * the row max of S'(t+1) is taken in stage 3 of iteration t (where the VALU used to idle under 8 MFMAs), leaving only a
+//     wave-uniform compare at the head of the next iteration.
+// VALU issue per wave and tile: 32 exp2 + 32 adds + 16 cvt_pk + 16 max3 (~550 cycles) instead of ~700 with the fma pass and an
+// unoverlapped max in front; the matrix pipe (1024 cycles per wave and tile, two waves per SIMD) is what every saved slot feeds.
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v3(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | V0 | V1], 16 KiB each
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.x / a.n_qtiles;
+    const int qt = blockIdx.x % a.n_qtiles;
+    if (a.n_splits > 1) {   // this workgroup's key range
+        const int kv0 = blockIdx.y * a.split_keys;
+        a.k += (int64_t)kv0 * a.sk;
+        a.v += (int64_t)kv0 * a.sv;
+        a.n_kv = min(a.n_kv - kv0, a.split_keys);
+    }
+    const int q0 = qt * QTILE + wave * QROWS_WAVE;
+    constexpr int KOFF = 0, VOFF = 2 * KV_TILE_BYTES;
+
+    bf16x8 qf[8];
+    {
+        const int qrow = min(q0 + lr, a.n_q - 1);
+        const bf16_t* qp = a.q + (int64_t)qrow * a.sq + head * D + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            // Q' = bf16(Q * scale * log2(e)): the scores leave the MFMA already in the exp2 domain (one rounding of q, 2^-9 relative)
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+            u32x4 sc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[j] = pack_bf2(bf2f_lo(raw[j]) * a.scale_log2e, bf2f_hi(raw[j]) * a.scale_log2e);
+            qf[ks] = __builtin_bit_cast(bf16x8, sc);
+        }
+    }
+
+    // ---- DMA addressing: wave w owns keys [8w, 8w+8) of a tile; piece i (0,1): key = 8w + 4i + (lane>>4), LDS chunk pos = lane&15
+    // Source address = wave-uniform tile base (scalar registers, advanced by scalar adds) + a per-lane byte offset that never
+    // changes: no vector integer work per tile.  Only a partial last tile takes the slow path that clamps rows to n_kv - 1.
+    const int dkey0 = 8 * wave + (lane >> 4), dcp = lane & 15;
+    const char* kbase = reinterpret_cast<const char*>(a.k + head * D);
+    const char* vbase = reinterpret_cast<const char*>(a.v + head * D);
+    uint32_t koff[2], voff[2], koff_last[2], voff_last[2];
+    const int last_tile = (a.n_kv + KVT - 1) / KVT - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = dkey0 + 4 * i;
+        const int kx = ((dcp ^ (key & 15)) << 4), vx = ((dcp ^ ((key & 3) << 2)) << 4);
+        koff[i] = (uint32_t)(key * (int)a.sk * 2 + kx);
+        voff[i] = (uint32_t)(key * (int)a.sv * 2 + vx);
+        const int keyl = min(key, a.n_kv - 1 - last_tile * KVT);      // rows past the end re-read the last valid row
+        koff_last[i] = (uint32_t)(keyl * (int)a.sk * 2 + kx);
+        voff_last[i] = (uint32_t)(keyl * (int)a.sv * 2 + vx);
+    }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 2048;   // 8 keys x 256 B; scalar: the DMA destination goes through M0
+    const int64_t k_tile_bytes = (int64_t)KVT * a.sk * 2, v_tile_bytes = (int64_t)KVT * a.sv * 2;
+    auto dma_k = [&](int tile, int buf) {
+        const char* tb = kbase + tile * k_tile_bytes;
+        const bool lastt = tile == last_tile;      // wave-uniform select, no branch
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(tb + (lastt ? koff_last[i] : koff[i])),
+                                             (lds_void_ptr)(smem + KOFF + buf * KV_TILE_BYTES + wave_lds + i * 1024), 16, 0, 0);
+    };
+    auto dma_v = [&](int tile, int buf) {
+        const char* tb = vbase + tile * v_tile_bytes;
+        const bool lastt = tile == last_tile;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(tb + (lastt ? voff_last[i] : voff[i])),
+                                             (lds_void_ptr)(smem + VOFF + buf * KV_TILE_BYTES + wave_lds + i * 1024), 16, 0, 0);
+    };
+
+    int kread[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = kb * 32 + lr;
+        kread[kb] = key * 256 + ((lh ^ (key & 15)) << 4);
+    }
+    const int vq = (lane & 15) >> 2, vp = lane & 3, vG = lane >> 4;
+    int vread;
+    {
+        const int key = 4 * (vG >> 1) + vq;
+        const int chunk16 = ((vG & 1) * 16 + 4 * vp) >> 3;
+        vread = key * 256 + ((chunk16 ^ ((key & 3) << 2)) << 4) + (vp & 1) * 8;
+    }
+
+    f32x16 oT[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oT[db][r] = 0.f;
+    // m_run: the row max the running sums are scaled by (log2 domain).  It is DEFERRED: it only moves when a tile's scores exceed
+    // it by more than THR, so P <= 2^THR instead of <= 1 (bf16 and fp32 keep their relative precision at any scale).  -m_run sits
+    // in all 16 registers of `negm`, the C operand of the first MFMA of every S chain: S' = K.Q'^T - m_run comes out of the matrix
+    // pipe ready for exp2 - no scale/subtract pass on the VALU at all.
+    float m_run = 0.f, l_run = 0.f;
+    f32x16 negm;
+    constexpr float THR = 8.0f;
+    const int ntiles = (a.n_kv + KVT - 1) / KVT;
+
+    auto qk = [&](f32x16 (&S)[2], int buf, const f32x16& c0) {
+        const char* kb_ = smem + KOFF + buf * KV_TILE_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_ + (kread[kb] ^ (ks << 5)));
+                S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? c0 : S[kb], 0, 0, 0);
+            }
+        }
+    };
+    auto exp_block = [&](const f32x16& S, bf16x8 (&pf)[2], float& ls) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(S[8 * s + j]);
+                const float p1 = __builtin_amdgcn_exp2f(S[8 * s + j + 1]);
+                ls += p0 + p1;
+                w[j >> 1] = pack_bf2(p0, p1);
+            }
+            pf[s] = __builtin_bit_cast(bf16x8, w);
+        }
+    };
+    auto pv_block = [&](const bf16x8 (&pf)[2], int kb, int buf) {
+        const char* vb_ = smem + VOFF + buf * KV_TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int koff = (kb * 32 + 16 * s) * 256;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const char* p0 = vb_ + ((vread + koff) ^ (db << 6));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * 256));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oT[db], 0, 0, 0);
+            }
+        }
+    };
+    // tail mask (last tile) + row max of a score tile (relative to m_run); VALU only, placed under the P.V MFMAs of the tile before
+    auto tile_max = [&](f32x16 (&Sc)[2], int t, bool last) -> float {
+        if (last && (a.n_kv & (KVT - 1))) {
+            const int kbase_i = t * KVT + 4 * lh;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase_i + kb * 32 + (r & 3) + 8 * (r >> 2);
+                    if (key >= a.n_kv) Sc[kb][r] = -INFINITY;
+                }
+        }
+        float mx = Sc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, Sc[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, Sc[1][r]);
+        return half_swap_max(mx);
+    };
+    // rare: some row of this tile exceeds the running max by more than THR -> move every row's max to its true value, rescale
+    // the sums, the scores of THIS tile (already relative to the old max) and the C operand of the next S chain
+    auto raise_max = [&](f32x16 (&Sc)[2], float mx) {
+        const float d = fmaxf(mx, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        l_run *= alpha;
+        m_run += d;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oT[db][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Sc[kb][r] -= d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+        asm volatile("" : "+v"(negm));      // 16 live registers, not 16 re-materialised moves per tile
+    };
+    // steady-state iteration: consumes Sc = S'(t) and its row max mx_c, produces Sn = S'(t+1) and mx_n
+    auto body_main = [&](f32x16 (&Sc)[2], f32x16 (&Sn)[2], int t, float mx_c, float& mx_n) {
+        if (t + 2 < ntiles) dma_k(t + 2, t & 1);
+        dma_v(t + 1, (t + 1) & 1);
+        if (__any(mx_c > THR)) raise_max(Sc, mx_c);
+        bf16x8 p0[2], p1[2];
+        float ls = 0.f;
+        qk(Sn, (t + 1) & 1, negm);      // stage 1: 16 MFMA  ||  exp of key block 0
+        exp_block(Sc[0], p0, ls);
+        pv_block(p0, 0, t & 1);         // stage 2: 8 MFMA   ||  exp of key block 1
+        exp_block(Sc[1], p1, ls);
+        pv_block(p1, 1, t & 1);         // stage 3: 8 MFMA   ||  row max of S'(t+1)
+        mx_n = tile_max(Sn, t + 1, t + 2 == ntiles);
+        l_run += ls;
+        __syncthreads();
+    };
+    auto body_last = [&](f32x16 (&Sc)[2], int t, float mx_c) {
+        if (__any(mx_c > THR)) raise_max(Sc, mx_c);
+        bf16x8 p0[2], p1[2];
+        float ls = 0.f;
+        exp_block(Sc[0], p0, ls);
+        pv_block(p0, 0, t & 1);
+        exp_block(Sc[1], p1, ls);
+        pv_block(p1, 1, t & 1);
+        l_run += ls;
+    };
+
+    f32x16 sA[2], sB[2];
+    dma_k(0, 0);
+    dma_v(0, 0);
+    if (ntiles > 1) dma_k(1, 1);
+    __syncthreads();
+    {
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        qk(sA, 0, zero);
+    }
+    // tile 0 fixes the initial max exactly: m_run = rowmax(S(0)), S'(0) = S(0) - m_run (the only explicit subtraction)
+    m_run = tile_max(sA, 0, ntiles == 1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sA[kb][r] -= m_run;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+    asm volatile("" : "+v"(negm));
+    __syncthreads();   // every wave finished reading K[0] before tile 2 is DMA'd over it
+    int t = 0;
+    float mxA = 0.f, mxB = 0.f;
+    for (; t + 2 < ntiles; t += 2) {
+        body_main(sA, sB, t, mxA, mxB);
+        body_main(sB, sA, t + 1, mxB, mxA);
+    }
+    if (t + 1 < ntiles) {
+        body_main(sA, sB, t, mxA, mxB);
+        body_last(sB, t + 1, mxB);
+    } else {
+        body_last(sA, t, mxA);
+    }
+
+    const float l_tot = half_swap_sum(l_run);
+    if (a.n_splits > 1 || a.partial) {   // partial result: O^T unnormalised (fp32) + (m, l); merged by attn_combine_kernel
+        const int qrow_p = q0 + lr;
+        if (qrow_p < a.n_q) {
+            const int64_t rowi = ((int64_t)blockIdx.y * a.n_q + qrow_p) * a.n_heads + head;
+            float* po = a.part_o + rowi * D + 4 * lh;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(po + db * 32 + g * 8) =
+                        make_float4(oT[db][4 * g], oT[db][4 * g + 1], oT[db][4 * g + 2], oT[db][4 * g + 3]);
+            if (lh == 0) {
+                a.part_ml[rowi * 2] = m_run;
+                a.part_ml[rowi * 2 + 1] = l_tot;
+            }
+        }
+        return;
+    }
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + lr;
+    if (qrow < a.n_q) {
+        bf16_t* op = a.o + (int64_t)qrow * a.so + head * D + 4 * lh;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w[0] = pack_bf2(oT[db][4 * g] * inv, oT[db][4 * g + 1] * inv);
+                w[1] = pack_bf2(oT[db][4 * g + 2] * inv, oT[db][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(op + db * 32 + g * 8) = w;
+            }
+    }
+}
+
+
 // merge the KV-split partials: O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m),  m = max_s m_s  (log2 domain)
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                             bf16_t* __restrict__ o, int64_t so, int n_q, int n_heads, int n_splits) {
@@ -334,7 +614,24 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     *reinterpret_cast<u32x2*>(o + row * so + head * D + d4 * 4) = w2;
 }
 
-HvPerDeviceOnce g_attn_lds_once;
+HvPerDeviceOnce g_attn_lds_once, g_attn3_lds_once;
+
+// HV_ATTN_V2=1: keep the previous kernel (same-box A/B, tests/test_gpu_attention_v3.py); read per call
+inline bool attn_use_v2() {
+    const char* e = std::getenv("HV_ATTN_V2");
+    return e && e[0] == '1';
+}
+
+int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
+    if (attn_use_v2()) {
+        if (hv_set_max_lds(g_attn_lds_once, (const void*)attn_fwd_kernel_v2, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
+        attn_fwd_kernel_v2<<<grid, dim3(512), ATT_LDS, stream>>>(a);
+    } else {
+        if (hv_set_max_lds(g_attn3_lds_once, (const void*)attn_fwd_kernel_v3, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
+        attn_fwd_kernel_v3<<<grid, dim3(512), ATT_LDS, stream>>>(a);
+    }
+    return HV_OK;
+}
 
 }  // namespace
 
@@ -358,7 +655,6 @@ extern "C" int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.n_q = n_q; a.n_kv = n_kv; a.n_heads = n_heads;
     a.n_qtiles = (n_q + QTILE - 1) / QTILE;
     a.scale_log2e = scale * 1.4426950408889634f;
-    if (hv_set_max_lds(g_attn_lds_once, (const void*)attn_fwd_kernel_v2, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
     // Load balance: workgroups are equal-cost items on 256 CUs; with only a few rounds (e.g. 3 heads per rank under Ulysses-8:
     // 1395 items = 5.45 rounds -> 6) a partially filled last round costs a whole item.  Splitting the key range in two makes
     // the items half as long (2790 items = 10.9 -> 11 half-rounds = 5.5): taken when it shortens the makespan by > 3 %.
@@ -374,7 +670,7 @@ extern "C" int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
             a.part_ml = a.part_o + (int64_t)2 * n_q * n_heads * D;
         }
     }
-    attn_fwd_kernel_v2<<<dim3((unsigned)(a.n_qtiles * n_heads), (unsigned)a.n_splits), dim3(512), ATT_LDS, stream>>>(a);
+    if (attn_launch(a, dim3((unsigned)(a.n_qtiles * n_heads), (unsigned)a.n_splits), stream) != HV_OK) return HV_ERR_LAUNCH;
     if (a.n_splits > 1) {
         const int64_t total = (int64_t)n_q * n_heads * 32;
         attn_combine_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(a.part_o, a.part_ml, a.o, a.so, n_q, n_heads,
@@ -407,8 +703,7 @@ extern "C" int hv_attn_partial_bf16(const void* q, const void* k, const void* v,
     a.part_o = (float*)part_o + (int64_t)slot * n_q * n_heads * D;
     a.part_ml = (float*)part_ml + (int64_t)slot * n_q * n_heads * 2;
     a.partial = 1;
-    if (hv_set_max_lds(g_attn_lds_once, (const void*)attn_fwd_kernel_v2, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
-    attn_fwd_kernel_v2<<<dim3((unsigned)(a.n_qtiles * n_heads), (unsigned)splits), dim3(512), ATT_LDS, stream>>>(a);
+    if (attn_launch(a, dim3((unsigned)(a.n_qtiles * n_heads), (unsigned)splits), stream) != HV_OK) return HV_ERR_LAUNCH;
     return hv_check_launch();
 }
 

@@ -26,10 +26,11 @@
 
 namespace {
 
-// HV_GEMM_2STAGE=1 in the environment keeps every plain GEMM on the 2-stage main loop (same-box A/B of the two loops)
+// HV_GEMM_2STAGE=1 in the environment keeps every plain GEMM on the 2-stage main loop.  Read per call (a getenv, no driver
+// work) so one process can A/B the two loops and check them against each other bit for bit (tests/test_gpu_gemm_pipeline.py).
 inline bool hv_gemm_force_2stage() {
-    static const bool v = [] { const char* e = std::getenv("HV_GEMM_2STAGE"); return e && e[0] == '1'; }();
-    return v;
+    const char* e = std::getenv("HV_GEMM_2STAGE");
+    return e && e[0] == '1';
 }
 
 constexpr int BM = 256, BK = 64;                 // BN is a template parameter: 256 (default) or 128 (N <= 128: VAE 128-channel convs)
