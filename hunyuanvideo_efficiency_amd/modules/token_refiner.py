@@ -63,16 +63,24 @@ class SingleTokenRefiner(nn.Module):
         self.individual_token_refiner = IndividualTokenRefiner(hidden_size, heads_num, depth, mlp_width_ratio, device, dtype)
         self._bufs = None
 
-    def run(self, text: torch.Tensor, t_f32: torch.Tensor, mask: Optional[torch.Tensor], out: torch.Tensor):
-        """text [L, in_channels] bf16, mask [1, L] (prefix mask) or None; writes the refined tokens into out [L, d]."""
+    def run(self, text: torch.Tensor, t_f32: torch.Tensor, mask: Optional[torch.Tensor], out: torch.Tensor,
+            cache: Optional[dict] = None):
+        """text [L, in_channels] bf16, mask [1, L] (prefix mask) or None; writes the refined tokens into out [L, d].
+        `cache` (a dict the caller keeps per prompt): the reference re-runs the whole refiner every step (models.py:638) although
+        only `t` changes; the timestep-INDEPENDENT prefix - input_embedder(text) and the masked mean that feeds c_embedder - is
+        computed once per prompt and reused (the two refiner blocks are modulated by t and run every step)."""
         from .attenion import n_valid_text
         L, d, H = text.shape[0], self.hidden_size, self.heads_num
         dev = text.device
         n_valid = L if mask is None else n_valid_text(mask)
-        mask_i32 = None if mask is None else mask[0].to(device=dev, dtype=torch.int32).contiguous()
+        hit = cache is not None and "emb" in cache and cache["emb"].shape == (L, d) and cache["emb"].device == dev
+        if hit:
+            mask_i32, ctx = cache["mask_i32"], cache["ctx"]
+        else:
+            mask_i32 = None if mask is None else mask[0].to(device=dev, dtype=torch.int32).contiguous()
+            ctx = ops.masked_mean(text, mask_i32)
         # c = t_embedder(t) + c_embedder(masked mean of the raw text states)      (token_refiner.py:220-229)
         t_aware = self.t_embedder.run(t_f32)
-        ctx = ops.masked_mean(text, mask_i32)
         c = self.c_embedder.run(ctx.reshape(1, -1), addend=t_aware)
         if self._bufs is None or self._bufs[0].shape[0] != L or self._bufs[0].device != dev:
             self._bufs = (torch.empty(L, d, dtype=BF16, device=dev), torch.empty(L, 3 * d, dtype=BF16, device=dev),
@@ -83,7 +91,12 @@ class SingleTokenRefiner(nn.Module):
             hid = torch.empty(L, mlp_hidden, dtype=BF16, device=dev)
             self._bufs = (norm, qkv, attn, hid)
         x = out
-        ops.gemm(text, self.input_embedder.weight, self.input_embedder.bias, out=x)
+        if hit:
+            x.copy_(cache["emb"])
+        else:
+            ops.gemm(text, self.input_embedder.weight, self.input_embedder.bias, out=x)
+            if cache is not None:
+                cache.update(emb=x.clone(), ctx=ctx, mask_i32=mask_i32)
         for blk in self.individual_token_refiner.blocks:
             ada = blk.adaLN_modulation[1]
             g = ops.linear_smallm(c, ada.weight, ada.bias, silu_in=True)
