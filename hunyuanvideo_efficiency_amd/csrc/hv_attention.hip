@@ -866,12 +866,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
     __syncthreads();   // every wave finished reading K[0] before tile 2 is DMA'd over it
     int t = 0;
     float mxA = 0.f, mxB = 0.f;
-    // in the loop tile t+1 <= ntiles-2 is never the last one: no mask code, the row max rides under the P.V MFMAs
-    for (; t + 2 < ntiles; t += 2) {
+    // inside the loop neither call may PRODUCE the last tile (t+1 and t+2 <= ntiles-2): no mask code there, the row max rides
+    // under the P.V MFMAs; the 1-3 tiles left over take the masked variant for the call that produces the last tile
+    for (; t + 3 < ntiles; t += 2) {
         body_main(sA, sB, t, mxA, mxB, std::false_type{});
         body_main(sB, sA, t + 1, mxB, mxA, std::false_type{});
     }
-    if (t + 1 < ntiles) {
+    const int rem = ntiles - t;
+    if (rem == 3) {
+        body_main(sA, sB, t, mxA, mxB, std::false_type{});
+        body_main(sB, sA, t + 1, mxB, mxA, std::true_type{});
+        body_last(sA, t + 2, mxA);
+    } else if (rem == 2) {
         body_main(sA, sB, t, mxA, mxB, std::true_type{});
         body_last(sB, t + 1, mxB);
     } else {

@@ -1,5 +1,5 @@
-"""GPU: the deferred-max attention kernel (attn_fwd_kernel_v3: running max in the C operand of the S chain, Q pre-scaled,
-threshold 2^8) against the oracle on inputs that FORCE its rare branch (guide rule 26: a bounded-random test never takes it):
+"""GPU: the deferred-max attention kernels (attn_fwd_kernel_v3 / v4: running max in the C operand of the S chain, Q pre-scaled,
+threshold 2^8; v4 = the shipped one, gap-scheduled body + bounds-checked buffer DMA) against the oracle on inputs that FORCE its rare branch (guide rule 26: a bounded-random test never takes it):
   * a late key far above everything before it -> raise_max fires mid-stream, for some rows only;
   * a steadily growing max: every tile raises it by < THR (deferred: never rescaled) vs by > THR (rescaled every tile);
   * the first tile all very negative (tile 0 fixes the initial max) and a huge first key (later tiles vanish);
@@ -45,12 +45,13 @@ def _check(ops, q, k, v, H, atol=8e-3):
     ref = _ref(q, k, v)
     got = _run(ops, q, k, v, H)
     torch.testing.assert_close(got.float().cpu(), ref, rtol=2 ** -7, atol=atol)
-    os.environ["HV_ATTN_V2"] = "1"
-    try:
-        old = _run(ops, q, k, v, H)
-    finally:
-        os.environ["HV_ATTN_V2"] = "0"
-    torch.testing.assert_close(got.float().cpu(), old.float().cpu(), rtol=2 ** -6, atol=atol)
+    for ver in ("2", "3"):          # the previous kernels on the same data: equal to bf16 rounding of the output
+        os.environ["HV_ATTN_VER"] = ver
+        try:
+            old = _run(ops, q, k, v, H)
+        finally:
+            os.environ["HV_ATTN_VER"] = "4"
+        torch.testing.assert_close(got.float().cpu(), old.float().cpu(), rtol=2 ** -6, atol=atol)
 
 
 def test_late_spike_raises_max_for_some_rows(ops):
