@@ -760,7 +760,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
     //   gaps  0-15  S'(t+1) chain (K fragments 2 gaps ahead) | exp/pack of P block 0, element g; of block 1, element g/2 (even g)
     //   gaps 16-23  O += V.P block 0 (V fragments 2 ahead)    | exp/pack of P block 1, elements 8..15
     //   gaps 24-31  O += V.P block 1                          | row max of S'(t+1), 4 values per gap
-    // NEXT_LAST: tile t+1 is the (possibly ragged) last one - its masked row max is taken after the gaps instead.
+    // NEXT_LAST: tile t+1 may be the (possibly ragged) last one - its masked row max is taken after the gaps instead.
     auto body_main = [&](f32x16 (&Sc)[2], f32x16 (&Sn)[2], int t, float mx_c, float& mx_n, auto next_last_c) {
         constexpr bool NEXT_LAST = decltype(next_last_c)::value;
         if (t + 2 < ntiles) dma_k(t + 2, t & 1);
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (NEXT_LAST) mx_n = tile_max(Sn, t + 1, true);
+        if (NEXT_LAST) mx_n = tile_max(Sn, t + 1, t + 2 == ntiles);
         else mx_n = half_swap_max(fmaxf(mxa, mxb));
         l_run += ls;
         __syncthreads();
@@ -872,17 +872,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
         body_main(sA, sB, t, mxA, mxB, std::false_type{});
         body_main(sB, sA, t + 1, mxB, mxA, std::false_type{});
     }
-    const int rem = ntiles - t;
-    if (rem == 3) {
-        body_main(sA, sB, t, mxA, mxB, std::false_type{});
-        body_main(sB, sA, t + 1, mxB, mxA, std::true_type{});
-        body_last(sA, t + 2, mxA);
-    } else if (rem == 2) {
+    // the 0-2 iterations left before the final tile: ONE more instance of the body (row max after the gaps, tail mask when the
+    // tile it produces is the last), scores handed back through a register copy instead of a second unrolled name swap
+    for (; t + 1 < ntiles; ++t) {
         body_main(sA, sB, t, mxA, mxB, std::true_type{});
-        body_last(sB, t + 1, mxB);
-    } else {
-        body_last(sA, t, mxA);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sA[kb] = sB[kb];
+        mxA = mxB;
     }
+    body_last(sA, t, mxA);
 
     const float l_tot = half_swap_sum(l_run);
     if (a.n_splits > 1 || a.partial) {   // partial result: O^T unnormalised (fp32) + (m, l); merged by attn_combine_kernel
