@@ -148,6 +148,9 @@ def main():
                     "default 1 = pure Ulysses")
     ap.add_argument("--use-fp8", action="store_true", help="BASELINE.json configs[3]: FP8 (e4m3) weight storage for the block linears, "
                     "dequantised per call into the bf16 MFMA GEMM (the reference's weight-only semantics)")
+    ap.add_argument("--fp8-mfma", action="store_true", help="with --use-fp8: run the block linears on the CDNA4 FP8 matrix cores "
+                    "(v_mfma_scale_f32_16x16x128_f8f6f4; activations quantised per token to e4m3) instead of dequantising the weights "
+                    "to bf16 per call - an opt-in approximation beyond the reference's weight-only FP8 (tests/test_gpu_fp8_mfma.py)")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-by-`value`) VAE tiled decode of the same video")
     a = ap.parse_args()
 
@@ -183,6 +186,11 @@ def main():
     if a.use_fp8:
         from hunyuanvideo_efficiency_amd.modules.fp8_optimization import convert_fp8_linear
         convert_fp8_linear(model, None, torch.bfloat16)
+        if a.fp8_mfma:
+            from hunyuanvideo_efficiency_amd.modules.fp8_optimization import enable_fp8_mfma
+            enable_fp8_mfma(model)
+    elif a.fp8_mfma:
+        raise SystemExit("--fp8-mfma needs --use-fp8 (FP8 weights)")
     if world > 1 or a.force_sp:
         from hunyuanvideo_efficiency_amd.inference import parallelize_transformer_module
         if a.ring_degree > 1:
@@ -279,10 +287,10 @@ def main():
                     break
         out = {
             "metric": ("denoise-steps/sec (" + {"720p129f": "720x1280x129f", "544p65f": "544x960x65f", "720p257f": "720x1280x257f"}.get(a.workload, a.workload)
-                       + ", HunyuanVideo DiT 20+40 blocks, " + ("bf16 compute, fp8 e4m3 weights)" if a.use_fp8 else "bf16)")) if not tiny else "denoise-steps/sec (tiny)",
+                       + ", HunyuanVideo DiT 20+40 blocks, " + (("fp8 e4m3 MFMA linears (per-token activation scales), bf16 attention, fp8 e4m3 weights)" if a.fp8_mfma else "bf16 compute, fp8 e4m3 weights)") if a.use_fp8 else "bf16)")) if not tiny else "denoise-steps/sec (tiny)",
             "value": a.steps / elapsed, "unit": "denoise-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (hash-generated latents/text embeddings, random-init weights)",
+            "dtype": "bf16+fp8(e4m3) linears" if a.fp8_mfma else "bf16", "data": "synthetic (hash-generated latents/text embeddings, random-init weights)",
             "config": {"workload": f"{a.workload}: latent 16x{T}x{H}x{W}, S_img={s_img}, S_txt={s_txt} (11 valid), "
                                    f"d={cfg.hidden_size}, heads={cfg.heads_num}, {cfg.mm_double_blocks_depth}+{cfg.mm_single_blocks_depth} blocks",
                        "parallelism": ("single GPU" + (" (SP code path forced on a 1-rank group)" if a.force_sp else "")) if world == 1 else (f"ulysses{world} (token-axis shard, RCCL all-to-all)" if a.ring_degree == 1 else f"ulysses{world // a.ring_degree} x ring{a.ring_degree} (RCCL all-to-all + point-to-point K/V ring)")},

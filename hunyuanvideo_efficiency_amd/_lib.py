@@ -42,6 +42,9 @@ SIGNATURES = {
     "hv_broadcast_row_bf16": [_p, _p, _l, _i, _l, _p],
     "hv_copy3d_bf16": [_p, _p, _i, _l, _i, _l, _l, _l, _l, _p],
     "hv_fp8_dequant_bf16": [_p, _p, _p, _l, _p],
+    "hv_ln_modulate_fp8": [_p, _p, _p, _p, _p, _l, _i, _l, _l, _f, _p],
+    "hv_quant_rows_fp8": [_p, _l, _p, _l, _p, _l, _i, _p],
+    "hv_gemm_fp8": [_p, _l, _p, _p, _l, _p, _p, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p, _p, _l, _p],
     "hv_gemm_f16": [_p, _l, _p, _l, _p, _i, _i, _i, _p, _l, _i, _p, _l, _p],
     "hv_conv3d_causal_f16": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p],
     "hv_groupnorm_affine_f16": [_p, _l, _l, _i, _i, _f, _p, _p, _p, _l, _p, _p],

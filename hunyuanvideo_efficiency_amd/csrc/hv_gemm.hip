@@ -43,6 +43,8 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 struct BF16T {
     typedef bf16x8 vec8;
+    static constexpr int ESIZE = 2;
+    static constexpr bool FP8 = false;
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ float lo(uint32_t w) { return bf2f_lo(w); }
     static __device__ __forceinline__ float hi(uint32_t w) { return bf2f_hi(w); }
@@ -51,6 +53,8 @@ struct BF16T {
 };
 struct F16T {
     typedef f16x8 vec8;
+    static constexpr int ESIZE = 2;
+    static constexpr bool FP8 = false;
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); }
     static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
@@ -58,6 +62,26 @@ struct F16T {
         return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)b) << 16);
     }
     static __device__ __forceinline__ float round(float f) { return (float)(_Float16)f; }
+};
+
+// FP8-MFMA path: both operands are OCP e4m3fn bytes (a 128-byte LDS row holds 128 k instead of 64), one
+// v_mfma_scale_f32_16x16x128_f8f6f4 per (m-rep, n-rep) and K-tile with all block scales = 1 (E8M0 127): 2x the bf16 FLOPs per
+// clock on the same bytes.  Outputs are bf16, so the epilogue helpers are BF16T's.  A lane's operand is its two 16-byte chunks
+// (fq, 4 + fq) of the row - the same chunks for A and W, so element j of lane group fq meets the same k in both (the only
+// requirement of the contraction; checked with exact integer data in tests/test_gpu_fp8_mfma.py).
+struct FP8T : BF16T {
+    static constexpr int ESIZE = 1;
+    static constexpr bool FP8 = true;
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    // 32 bytes of one LDS row = one lane's operand: the two 16-byte chunks are read straight into the halves of an 8-register tuple
+    static __device__ __forceinline__ i32x8 load2(const char* p_lo, const char* p_hi) {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(p_lo), hi = *reinterpret_cast<const i32x4*>(p_hi);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    static __device__ __forceinline__ f32x4 mfma8(i32x8 a, i32x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /*A: fp8 e4m3*/, 0 /*B: fp8 e4m3*/, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    }
 };
 
 struct GemmArgs {
@@ -71,6 +95,8 @@ struct GemmArgs {
     const uint16_t* gate;
     const uint16_t* res; int64_t ld_res;
     float* out_f32;            // if set: plain fp32 result (acc + bias) to out_f32[m*ld0 + n], nothing else
+    const float* a_scale;      // FP8 path: per-row activation scales [M] (fp32) ...
+    const uint16_t* w_scale;   // ... and the per-tensor weight scale (one bf16, fp8_optimization.py `fp8_scale`): y = acc * a_scale[m] * w_scale
     int tiles_m, tiles_n;
     // conv mode (ksz = 3): output grid cT x cH x cW, source tensor sT x sH x sW (differs when upsampling), cin per tap
     int cT, cH, cW, sT, sH, sW, up_t, up_hw, cin;
@@ -100,6 +126,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         }
     };
     const int mrow0 = m0 + wm * 128 + fr;
+    const float wsc = g.w_scale ? bf2f(*g.w_scale) : 1.0f;
 #pragma unroll
     for (int np = 0; np < NREP / 2; ++np) {
         const int n = n0 + wn * (BN / 4) + np * 32 + fq * 8;
@@ -120,10 +147,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
             const int m = mrow0 + mi * 16;
             if (m >= g.M) continue;
             float v[8];
+            const float sc = g.a_scale ? g.a_scale[m] * wsc : 1.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = acc[mi][2 * np][r] + b[r];
-                v[4 + r] = acc[mi][2 * np + 1][r] + b[4 + r];
+                v[r] = acc[mi][2 * np][r] * sc + b[r];
+                v[4 + r] = acc[mi][2 * np + 1][r] * sc + b[4 + r];
             }
             if (g.out_f32) {
                 float4* o = reinterpret_cast<float4*>(g.out_f32 + (int64_t)m * g.ld0 + n);
@@ -377,14 +405,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int arow = i * 128 + h * 64 + srow;                       // tile row of LDS row (i*64 + srow) of half-tile Am<h>
-            a_o[h][i] = (uint32_t)(((int64_t)(min(m0 + arow, g.M - 1) - m0) * g.lda + ((scp ^ swz_a(srow)) << 3)) * 2);
+            a_o[h][i] = (uint32_t)((int64_t)(min(m0 + arow, g.M - 1) - m0) * g.lda * DT::ESIZE + ((scp ^ swz_a(srow)) << 4));
             const int lr = i * 64 + srow;                                   // LDS row of half-tile Bn<h>
             const int wrow = (lr >> 5) * 64 + h * 32 + (lr & 31);           // wave column (lr>>5), its W rows [h*32, h*32+32)
-            w_o[h][i] = (uint32_t)(((int64_t)(min(n0 + wrow, g.N - 1) - n0) * g.ldw + ((scp ^ swz_w(lr)) << 3)) * 2);
+            w_o[h][i] = (uint32_t)((int64_t)(min(n0 + wrow, g.N - 1) - n0) * g.ldw * DT::ESIZE + ((scp ^ swz_w(lr)) << 4));
         }
     const int wave_lds = wave * 1024;
-    const char* a_tile = reinterpret_cast<const char*>(g.A + (int64_t)m0 * g.lda);
-    const char* w_tile = reinterpret_cast<const char*>(g.W + (int64_t)n0 * g.ldw);
+    const char* a_tile = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * DT::ESIZE;
+    const char* w_tile = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * DT::ESIZE;
 
     // half-tile J (0 Am0, 1 Bn0, 2 Bn1, 3 Am1) of K-tile `tile` into buffer `buf` (wave-uniform: the destination goes through M0)
     auto stage = [&](auto Jc, int buf, int tile) {
@@ -414,33 +442,49 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    vec8 af[4][2], wf0[2][2], wf1[2][2];
+    // fragments: 16-bit types keep the two k-steps of a row apart ([..][ks], one MFMA each); fp8 reads both 16-byte chunks into
+    // ONE 8-register operand (a 128-deep MFMA).  Same bytes, same addresses, same registers.
+    typedef typename std::conditional<DT::FP8, __attribute__((ext_vector_type(8))) int, vec8>::type frag_t;
+    constexpr int NKS = DT::FP8 ? 1 : 2;
+    frag_t af[4][NKS], wf0[2][NKS], wf1[2][NKS];
 
     auto readA = [&](auto BUFc, auto MHc) {
         constexpr int BUF = decltype(BUFc)::value, MH = decltype(MHc)::value;
         const char* base = smem + BUF * BUF8_BYTES + (MH ? 3 : 0) * HT_BYTES;
+        if constexpr (DT::FP8) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int mi = 0; mi < 4; ++mi) af[mi][0] = DT::load2(base + (a_rd + mi * 2048), base + ((a_rd ^ 64) + mi * 2048));
+        } else {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[mi][ks] = *reinterpret_cast<const vec8*>(base + ((a_rd ^ (ks << 6)) + mi * 2048));
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) af[mi][ks] = *reinterpret_cast<const vec8*>(base + ((a_rd ^ (ks << 6)) + mi * 2048));
+        }
     };
-    auto readB = [&](auto BUFc, auto NHc, vec8 (&wf)[2][2]) {
+    auto readB = [&](auto BUFc, auto NHc, frag_t (&wf)[2][NKS]) {
         constexpr int BUF = decltype(BUFc)::value, NH = decltype(NHc)::value;
         const char* base = smem + BUF * BUF8_BYTES + (1 + NH) * HT_BYTES;
+        if constexpr (DT::FP8) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int nl = 0; nl < 2; ++nl) wf[nl][0] = DT::load2(base + (w_rd + nl * 512), base + ((w_rd ^ 64) + nl * 512));
+        } else {
 #pragma unroll
-            for (int nl = 0; nl < 2; ++nl) wf[nl][ks] = *reinterpret_cast<const vec8*>(base + ((w_rd ^ (ks << 6)) + nl * 512));
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl) wf[nl][ks] = *reinterpret_cast<const vec8*>(base + ((w_rd ^ (ks << 6)) + nl * 512));
+        }
     };
-    auto mma = [&](auto MHc, auto NHc, const vec8 (&wf)[2][2]) {
+    auto mma = [&](auto MHc, auto NHc, const frag_t (&wf)[2][NKS]) {
         constexpr int MH = decltype(MHc)::value, NH = decltype(NHc)::value;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int nl = 0; nl < 2; ++nl)
-                    acc[MH * 4 + mi][NH * 2 + nl] = DT::mfma(wf[nl][ks], af[mi][ks], acc[MH * 4 + mi][NH * 2 + nl]);
+                for (int nl = 0; nl < 2; ++nl) {
+                    if constexpr (DT::FP8) acc[MH * 4 + mi][NH * 2 + nl] = DT::mfma8(wf[nl][ks], af[mi][ks], acc[MH * 4 + mi][NH * 2 + nl]);
+                    else acc[MH * 4 + mi][NH * 2 + nl] = DT::mfma(wf[nl][ks], af[mi][ks], acc[MH * 4 + mi][NH * 2 + nl]);
+                }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -494,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     // ---- prologue: half-tiles 0..6 (K-tile 0 and Am0, Bn0, Bn1 of K-tile 1); phase 0 reads half-tiles 0 and 1.
     // K-tile t lives in buffer (t + par) & 1 with par = (number of steady tiles) & 1, so that the unrolled pair loop and the two
     // tail tiles always see buffers (0, 1): an odd steady count is absorbed by ONE peeled tile in front, not by a second copy of the tail.
-    const int nkt = g.K / BK;      // >= 3 (host-side dispatch)
+    const int nkt = g.K * DT::ESIZE / (BK * 2);      // 128-byte K-tiles; >= 3 (host-side dispatch)
     const int ns = nkt - 2;        // steady tiles 0 .. nkt-3
     const int par = ns & 1;
     stage(I0{}, par, 0); stage(I1{}, par, 0); stage(I2{}, par, 0); stage(I3{}, par, 0);
@@ -581,6 +625,20 @@ extern "C" int hv_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     if (rc != HV_OK) return rc;
     if (M == 0) return HV_OK;
     return launch<BF16T, false>(g, stream);
+}
+
+extern "C" int hv_gemm_fp8(const void* A_q, int64_t lda, const float* a_row_scale, const void* W_q, int64_t ldw, const void* w_scale_bf16,
+                           const void* bias, int M, int N, int K, void* out0, int64_t ld0, int act0, int n_split, void* out1,
+                           int64_t ld1, int act1, const void* gate, const void* res, int64_t ld_res, hipStream_t stream) {
+    // K % 128 == 0 and K >= 384 (three 128-byte K-tiles: the pipelined loop is the only fp8 main loop); operand row strides % 16
+    if (!a_row_scale || !w_scale_bf16 || K < 384 || (K % 128) || (lda & 15) || (ldw & 15)) return HV_ERR_ARG;
+    GemmArgs g;
+    int rc = fill_common(g, A_q, lda, W_q, ldw, bias, M, N, K, out0, ld0, act0, n_split, out1, ld1, act1, gate, res, ld_res);
+    if (rc != HV_OK) return rc;
+    g.a_scale = a_row_scale;
+    g.w_scale = (const uint16_t*)w_scale_bf16;
+    if (M == 0) return HV_OK;
+    return launch_gemm8<FP8T>(g, stream);
 }
 
 extern "C" int hv_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, int M, int N, int K,

@@ -92,6 +92,161 @@ extern "C" int hv_ln_modulate_bf16(const void* x, const void* shift_or_bias, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// FP8-MFMA path (opt-in; BASELINE.json config 4): per-token (row) dynamic quantisation of a GEMM A operand to OCP e4m3fn,
+//   s_row = max|y_row| / 448,  q = e4m3(clamp(y / s_row, +-448))  (round to nearest even),  y_row ~= q * s_row.
+// The row scale is applied by the GEMM epilogue (hv_gemm_fp8) together with the per-tensor weight scale of the reference's FP8
+// checkpoints (fp8_optimization.py:85-100).  pack4: four fp32 -> one dword of 4 e4m3 bytes (v_cvt_pk_fp8_f32 x2).
+__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
+    uint32_t w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return w;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float clamp448(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }
+
+// K1 with an fp8 output: y = bf16(LN(x) * bf16(1 + scale) + shift) exactly as ln_mod_kernel mode 0 (the bf16 rounding of the
+// reference contract is kept, so the ONLY new error is the e4m3 rounding), then the per-row quantisation above.
+template <int MAXC>
+__global__ __launch_bounds__(256) void ln_mod_fp8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ add,
+                                                          const bf16_t* __restrict__ mul, uint8_t* __restrict__ out,
+                                                          float* __restrict__ row_scale, int64_t M, int D, int64_t ldx,
+                                                          int64_t ldo, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nchunk = D >> 3;
+    const bf16_t* xr = x + row * ldx;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            unpack8(*reinterpret_cast<const u32x4*>(xr + ch * 8), v[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[c][j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float d = v[c][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            float m[8], a[8];
+            if (mul) {
+                unpack8(*reinterpret_cast<const u32x4*>(mul + ch * 8), m);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = rbf(1.0f + m[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = 1.0f;
+            }
+            if (add) unpack8(*reinterpret_cast<const u32x4*>(add + ch * 8), a);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[c][j] = rbf((v[c][j] - mean) * rstd * m[j] + a[j]);
+                amax = fmaxf(amax, fabsf(v[c][j]));
+            }
+        }
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) row_scale[row] = sc;
+    uint8_t* orow = out + row * ldo;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            u32x2 w;
+            w[0] = pack4_fp8(clamp448(v[c][0] * inv), clamp448(v[c][1] * inv), clamp448(v[c][2] * inv), clamp448(v[c][3] * inv));
+            w[1] = pack4_fp8(clamp448(v[c][4] * inv), clamp448(v[c][5] * inv), clamp448(v[c][6] * inv), clamp448(v[c][7] * inv));
+            *reinterpret_cast<u32x2*>(orow + ch * 8) = w;
+        }
+    }
+}
+
+extern "C" int hv_ln_modulate_fp8(const void* x, const void* shift, const void* scale, void* out_q, float* out_row_scale, int64_t M,
+                                  int D, int64_t ldx, int64_t ldq, float eps, hipStream_t stream) {
+    if (!x || !out_q || !out_row_scale || M < 0 || D <= 0 || (D & 7) || D > 4096 || (ldx & 7) || (ldq & 15)) return HV_ERR_ARG;
+    if (M == 0) return HV_OK;
+    dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    const bf16_t *xp = (const bf16_t*)x, *ap = (const bf16_t*)shift, *mp = (const bf16_t*)scale;
+    if (D <= 512)
+        ln_mod_fp8_kernel<1><<<grid, block, 0, stream>>>(xp, ap, mp, (uint8_t*)out_q, out_row_scale, M, D, ldx, ldq, eps);
+    else if (D <= 2048)
+        ln_mod_fp8_kernel<4><<<grid, block, 0, stream>>>(xp, ap, mp, (uint8_t*)out_q, out_row_scale, M, D, ldx, ldq, eps);
+    else if (D <= 3072)
+        ln_mod_fp8_kernel<6><<<grid, block, 0, stream>>>(xp, ap, mp, (uint8_t*)out_q, out_row_scale, M, D, ldx, ldq, eps);
+    else
+        ln_mod_fp8_kernel<8><<<grid, block, 0, stream>>>(xp, ap, mp, (uint8_t*)out_q, out_row_scale, M, D, ldx, ldq, eps);
+    return hv_check_launch();
+}
+
+// bf16 rows [M, K] (row stride ldx) -> e4m3 rows + row scales; one wave per row, two passes over the row (the second one hits L2:
+// a row is at most 30 KiB).  K % 8 == 0.
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out,
+                                                              int64_t ldo, float* __restrict__ row_scale, int64_t M, int K) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16_t* xr = x + row * ldx;
+    const int nchunk = K >> 3;
+    float amax = 0.f;
+    for (int ch = lane; ch < nchunk; ch += 64) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + ch * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) row_scale[row] = sc;
+    uint8_t* orow = out + row * ldo;
+    for (int ch = lane; ch < nchunk; ch += 64) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + ch * 8), f);
+        u32x2 w;
+        w[0] = pack4_fp8(clamp448(f[0] * inv), clamp448(f[1] * inv), clamp448(f[2] * inv), clamp448(f[3] * inv));
+        w[1] = pack4_fp8(clamp448(f[4] * inv), clamp448(f[5] * inv), clamp448(f[6] * inv), clamp448(f[7] * inv));
+        *reinterpret_cast<u32x2*>(orow + ch * 8) = w;
+    }
+}
+
+extern "C" int hv_quant_rows_fp8(const void* x, int64_t ldx, void* out_q, int64_t ldq, float* out_row_scale, int64_t M, int K,
+                                 hipStream_t stream) {
+    if (!x || !out_q || !out_row_scale || M < 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldq & 15)) return HV_ERR_ARG;
+    if (M == 0) return HV_OK;
+    quant_rows_fp8_kernel<<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream>>>((const bf16_t*)x, ldx, (uint8_t*)out_q, ldq,
+                                                                                  out_row_scale, M, K);
+    return hv_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
 // In-place per-head RMSNorm (+ RoPE) of the q and k thirds of fused QKV rows [n_rows, ld], head_dim 128.
 //   y = bf16( x_f32 * rsqrt(mean(x^2)+eps) )  -> y = bf16(y * w)     (cast BEFORE the gain, norm_layers.py:56-58)
 //   rope rows (row < n_rope): out[2i]   = y[2i]*cos[2i]   - y[2i+1]*sin[2i]

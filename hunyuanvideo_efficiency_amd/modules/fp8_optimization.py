@@ -52,6 +52,20 @@ def quantize_weight(w: torch.Tensor):
     return q.to(torch.float8_e4m3fn), scale
 
 
+def enable_fp8_mfma(module, enable: bool = True) -> int:
+    """Opt-in FP8 COMPUTE (BASELINE.json configs[3] "fp8 weight path (CDNA4 fp8 MFMA)"): after convert_fp8_linear, every
+    double / single block runs its Linears on v_mfma_scale_f32_16x16x128_f8f6f4 - the stored e4m3 weights go to the matrix cores
+    as they are (no per-forward dequantisation, `fp8_scale` applied in the GEMM epilogue) and the activations are quantised per
+    token to e4m3 (models._gemm / models._ln).  This is NOT the reference's arithmetic (its FP8 is weight-only): it adds the e4m3
+    rounding of the activations; tolerance and the quantisation-aware oracle: tests/test_gpu_fp8_mfma.py."""
+    n = 0
+    for key, block in module.named_modules():
+        if hasattr(block, "hybrid_seq_parallel_attn") and hasattr(block, "run"):
+            block.fp8_mfma = bool(enable)
+            n += 1
+    return n
+
+
 def convert_fp8_linear(module, dit_weight_path: Optional[str], original_dtype, params_to_keep={}, fp8_map: Optional[Dict] = None):
     """fp8_optimization.py:82-100.  `<dit_weight_path>_map.pt` holds the per-layer scales of a real FP8 checkpoint and is
     read with torch.load(weights_only=True) (never unpickled).  Without a checkpoint (random-init benchmarks) pass

@@ -42,9 +42,59 @@ class _Workspace:
         self.cat = torch.empty(s, d + mlp, dtype=BF16, device=device)
         self.patches = None
         self.final = None
+        # FP8-MFMA path (allocated on first use): per-token quantised A operands + their row scales
+        self.xq = self.xs = self.catq = self.cats = None
+
+    def fp8_buffers(self):
+        if self.xq is None:
+            s, d = self.x.shape
+            dev = self.x.device
+            self.xq = torch.empty(s, d, dtype=torch.float8_e4m3fn, device=dev)
+            self.xs = torch.empty(s, dtype=torch.float32, device=dev)
+            self.catq = torch.empty(s, self.cat.shape[1], dtype=torch.float8_e4m3fn, device=dev)
+            self.cats = torch.empty(s, dtype=torch.float32, device=dev)
+        return self
 
 
-def _sp_chunked_qkv(sp, ws: _Workspace, w, b, q_norm_w, k_norm_w, cos, sin, s_img: int, cu1: int, n_rope: int, H: int, d: int):
+def _use_fp8_mfma(block, *layers) -> bool:
+    """FP8 MFMA GEMMs for this block: opted in (fp8_optimization.enable_fp8_mfma), every Linear involved stores e4m3 weights and
+    has a reduction length hv_gemm_fp8 takes (K % 128 == 0, K >= 384: three 128-byte K-tiles); otherwise the block keeps the
+    reference's weight-only semantics (per-call dequantisation + bf16 MFMA)."""
+    return bool(getattr(block, "fp8_mfma", False)) and all(
+        l.weight.dtype == torch.float8_e4m3fn and l.in_features >= 384 and l.in_features % 128 == 0 for l in layers)
+
+
+def _ln(ws: _Workspace, lo: int, hi: int, shift, scale, fp8: bool):
+    """K1 on rows [lo, hi): bf16 into ws.xmod, or (FP8-MFMA path) e4m3 + row scales into ws.xq / ws.xs."""
+    if fp8:
+        ws.fp8_buffers()
+        ops.ln_modulate_fp8(ws.x[lo:hi], shift, scale, out_q=ws.xq[lo:hi], out_scale=ws.xs[lo:hi])
+    else:
+        ops.ln_modulate(ws.x[lo:hi], shift, scale, out=ws.xmod[lo:hi])
+
+
+def _gemm(ws: _Workspace, layer, src: str, lo: int, hi: int, fp8: bool, wrows: Optional[slice] = None, **epi):
+    """One block Linear on rows [lo, hi).  `src` names the A operand: "xmod" (the LayerNorm output of _ln), "attn" = cat[:, :d],
+    "hid" = cat[:, d:], "cat" = the whole [attn | mlp] row.  bf16 path: hv_gemm_bf16 on layer.w() (for an FP8 layer the weight
+    is dequantised per call - the reference's semantics).  FP8-MFMA path: the stored e4m3 weight goes to the matrix cores as is and
+    the A operand is quantised per token (LayerNorm outputs already are; the others are quantised here)."""
+    d = ws.x.shape[1]
+    cols = {"xmod": None, "attn": slice(0, d), "hid": slice(d, None), "cat": slice(None)}[src]
+    b = layer.bias if wrows is None or layer.bias is None else layer.bias[wrows]
+    if not fp8:
+        a = ws.xmod[lo:hi] if src == "xmod" else ws.cat[lo:hi, cols]
+        w = layer.w()
+        return ops.gemm(a, w if wrows is None else w[wrows], b, **epi)
+    ws.fp8_buffers()
+    if src == "xmod":
+        aq, asc = ws.xq[lo:hi], ws.xs[lo:hi]
+    else:
+        aq, asc = ops.quant_rows_fp8(ws.cat[lo:hi, cols], out_q=ws.catq[lo:hi, cols], out_scale=ws.cats[lo:hi])
+    w8 = layer.weight if wrows is None else layer.weight[wrows]
+    return ops.gemm_fp8(aq, asc, w8, layer.fp8_scale, b, **epi)
+
+
+def _sp_chunked_qkv(sp, ws: _Workspace, layer, fp8, q_norm_w, k_norm_w, cos, sin, s_img: int, cu1: int, n_rope: int, H: int, d: int):
     """Sequence-parallel form of "QKV GEMM -> RMSNorm/RoPE -> all-to-all" for the local image rows [0, s_img): q, k and v are
     produced by three column-chunk MFMA GEMMs (rows [c*d, (c+1)*d) of the fused weight) and each chunk is handed to the
     Ulysses object as soon as it is normalised, so its RCCL all-to-all overlaps the next chunk's GEMM.  The text rows
@@ -53,7 +103,7 @@ def _sp_chunked_qkv(sp, ws: _Workspace, w, b, q_norm_w, k_norm_w, cos, sin, s_im
     sp.begin(s_img, cu1 - s_img, H, ws.qkv.device)
     for c, which, norm_w in ((0, "q", q_norm_w), (1, "k", k_norm_w), (2, "v", None)):
         chunk = ws.qkv[:s_img, c * d:(c + 1) * d]
-        ops.gemm(ws.xmod[:s_img], w[c * d:(c + 1) * d], None if b is None else b[c * d:(c + 1) * d], out=chunk)
+        _gemm(ws, layer, "xmod", 0, s_img, fp8, wrows=slice(c * d, (c + 1) * d), out=chunk)
         if norm_w is not None:
             # the kernel normalises 2 x (H/2) head vectors: with both halves given the same gain that is this chunk's H heads
             ops.qknorm_rope_(chunk, norm_w, norm_w, cos, sin, n_rope, H // 2, (H // 2) * 128)
@@ -98,19 +148,21 @@ class MMDoubleStreamBlock(nn.Module):
         sp = self.hybrid_seq_parallel_attn
         overlap = sp is not None and hasattr(sp, "send") and H % 2 == 0
         mods = {}
+        fp8 = {s: _use_fp8_mfma(self, getattr(self, f"{s}_attn_qkv"), getattr(self, f"{s}_attn_proj"), getattr(self, f"{s}_mlp").fc1,
+                                getattr(self, f"{s}_mlp").fc2) for s in ("img", "txt")}
         for s, lo, hi, n_rope in streams:
             mod = getattr(self, f"{s}_mod")
             m = ops.linear_smallm(vec, mod.linear.w(), mod.linear.bias, silu_in=True)  # [1, 6d]
             mods[s] = [m[0, i * d:(i + 1) * d] for i in range(6)]   # shift1, scale1, gate1, shift2, scale2, gate2
             sh1, sc1 = mods[s][0], mods[s][1]
-            ops.ln_modulate(ws.x[lo:hi], sh1, sc1, out=ws.xmod[lo:hi])
+            _ln(ws, lo, hi, sh1, sc1, fp8[s])
             qkv_l = getattr(self, f"{s}_attn_qkv")
             qw, kw = getattr(self, f"{s}_attn_q_norm").weight, getattr(self, f"{s}_attn_k_norm").weight
             if overlap and s == "img":
                 # q / k / v as three column-chunk GEMMs; each chunk's all-to-all travels while the next chunk's GEMM runs
-                _sp_chunked_qkv(sp, ws, qkv_l.w(), qkv_l.bias, qw, kw, cos, sin, s_img, cu1, n_rope, H, d)
+                _sp_chunked_qkv(sp, ws, qkv_l, fp8[s], qw, kw, cos, sin, s_img, cu1, n_rope, H, d)
             else:
-                ops.gemm(ws.xmod[lo:hi], qkv_l.w(), qkv_l.bias, out=ws.qkv[lo:hi])
+                _gemm(ws, qkv_l, "xmod", lo, hi, fp8[s], out=ws.qkv[lo:hi])
                 ops.qknorm_rope_(ws.qkv[lo:hi], qw, kw, cos, sin, n_rope, H, d)
         if overlap:
             sp.attend(ws.cat, ws.cat.stride(0))
@@ -122,11 +174,10 @@ class MMDoubleStreamBlock(nn.Module):
             _, _, g1, sh2, sc2, g2 = mods[s]
             proj, mlp = getattr(self, f"{s}_attn_proj"), getattr(self, f"{s}_mlp")
             x = ws.x[lo:hi]
-            ops.gemm(ws.cat[lo:hi, :d], proj.w(), proj.bias, out=x, gate=g1, res=x)
-            ops.ln_modulate(x, sh2, sc2, out=ws.xmod[lo:hi])
-            hbuf = ws.cat[lo:hi, d:]
-            ops.gemm(ws.xmod[lo:hi], mlp.fc1.w(), mlp.fc1.bias, out=hbuf, act=ops.ACT_GELU_TANH)
-            ops.gemm(hbuf, mlp.fc2.w(), mlp.fc2.bias, out=x, gate=g2, res=x)
+            _gemm(ws, proj, "attn", lo, hi, fp8[s], out=x, gate=g1, res=x)
+            _ln(ws, lo, hi, sh2, sc2, fp8[s])
+            _gemm(ws, mlp.fc1, "xmod", lo, hi, fp8[s], out=ws.cat[lo:hi, d:], act=ops.ACT_GELU_TANH)
+            _gemm(ws, mlp.fc2, "hid", lo, hi, fp8[s], out=x, gate=g2, res=x)
 
     def forward(self, img, txt, vec, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                 freqs_cis: tuple = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -176,28 +227,27 @@ class MMSingleStreamBlock(nn.Module):
         d, H = self.hidden_size, self.heads_num
         m = ops.linear_smallm(vec, self.modulation.linear.w(), self.modulation.linear.bias, silu_in=True)
         shift, scale, gate = m[0, :d], m[0, d:2 * d], m[0, 2 * d:]
-        ops.ln_modulate(ws.x, shift, scale, out=ws.xmod)
+        fp8 = _use_fp8_mfma(self, self.linear1, self.linear2)
+        s_all = ws.x.shape[0]
+        _ln(ws, 0, s_all, shift, scale, fp8)
         sp = self.hybrid_seq_parallel_attn
         n_rope = s_img if cos is not None else 0
         if sp is not None and hasattr(sp, "send") and H % 2 == 0:
             # sequence parallel: q | k | v | mlp as four column-chunk GEMMs of linear1; the all-to-all of each attention chunk
             # runs on RCCL's stream under the following chunk's MFMA GEMM (the 12288-wide mlp chunk covers the v exchange)
-            w1, b1 = self.linear1.w(), self.linear1.bias
-            s_tot = ws.x.shape[0]
             # text rows of all three chunks first (they are the joint tensors every send needs)
-            ops.gemm(ws.xmod[s_img:], w1[:3 * d], b1[:3 * d], out=ws.qkv[s_img:])
+            _gemm(ws, self.linear1, "xmod", s_img, s_all, fp8, wrows=slice(0, 3 * d), out=ws.qkv[s_img:])
             ops.qknorm_rope_(ws.qkv[s_img:], self.q_norm.weight, self.k_norm.weight, None, None, 0, H, d)
-            _sp_chunked_qkv(sp, ws, w1, b1, self.q_norm.weight, self.k_norm.weight, cos, sin, s_img, cu1, n_rope, H, d)
-            ops.gemm(ws.xmod, w1[3 * d:], b1[3 * d:], out=ws.cat[:, d:], act=ops.ACT_GELU_TANH)
+            _sp_chunked_qkv(sp, ws, self.linear1, fp8, self.q_norm.weight, self.k_norm.weight, cos, sin, s_img, cu1, n_rope, H, d)
+            _gemm(ws, self.linear1, "xmod", 0, s_all, fp8, wrows=slice(3 * d, None), out=ws.cat[:, d:], act=ops.ACT_GELU_TANH)
             sp.attend(ws.cat, ws.cat.stride(0))
             pad_segment_attention_(ws.qkv, ws.cat, cu1, H, d)
         else:
             # linear1: cols [0,3d) -> qkv ; cols [3d, 3d+mlp) -> GELU-tanh -> cat[:, d:]   (models.py:339-341,392)
-            ops.gemm(ws.xmod, self.linear1.w(), self.linear1.bias, out=ws.qkv, n_split=3 * d, out1=ws.cat[:, d:],
-                     act1=ops.ACT_GELU_TANH)
+            _gemm(ws, self.linear1, "xmod", 0, s_all, fp8, out=ws.qkv, n_split=3 * d, out1=ws.cat[:, d:], act1=ops.ACT_GELU_TANH)
             ops.qknorm_rope_(ws.qkv, self.q_norm.weight, self.k_norm.weight, cos, sin, n_rope, H, d)
             segment_attention_(sp, ws.qkv, ws.cat, s_img, cu1, H, d)
-        ops.gemm(ws.cat, self.linear2.w(), self.linear2.bias, out=ws.x, gate=gate, res=ws.x)
+        _gemm(ws, self.linear2, "cat", 0, s_all, fp8, out=ws.x, gate=gate, res=ws.x)
 
     def forward(self, x, vec, txt_len, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                 freqs_cis: Tuple[torch.Tensor, torch.Tensor] = None) -> torch.Tensor:

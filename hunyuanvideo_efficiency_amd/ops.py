@@ -274,6 +274,74 @@ def fp8_dequant(w8, scale_bf16, out_bf16):
     return out_bf16
 
 
+# ---------------------------------------------------------------------------------------------- FP8-MFMA path (opt-in)
+FP8 = torch.float8_e4m3fn
+
+
+def ln_modulate_fp8(x, shift=None, scale=None, out_q=None, out_scale=None, eps: float = 1e-6):
+    """bf16(LN(x)*bf16(1+scale)+shift) quantised per row -> (e4m3 rows [M, D], fp32 row scales [M])."""
+    _chk(x, BF16, "x")
+    m, d, ldx = _rows(x, "x")
+    if out_q is None:
+        out_q = torch.empty(m, d, dtype=FP8, device=x.device)
+    if out_scale is None:
+        out_scale = torch.empty(m, dtype=torch.float32, device=x.device)
+    assert out_q.dtype == FP8 and out_q.is_cuda and out_q.shape[-1] == d and out_q.stride(-1) == 1 and out_scale.numel() >= m
+    for t, n in ((shift, "shift"), (scale, "scale")):
+        if t is not None:
+            _chk(t, BF16, n)
+            assert t.numel() == d and t.is_contiguous()
+    _lib.call("ln_modulate_fp8", x, shift, scale, out_q, out_scale, m, d, ldx, out_q.stride(-2) if out_q.dim() > 1 else d, eps)
+    return out_q, out_scale
+
+
+def quant_rows_fp8(x, out_q=None, out_scale=None):
+    """bf16 rows [M, K] -> (e4m3 rows, fp32 row scales): per-token dynamic quantisation of a GEMM A operand."""
+    _chk(x, BF16, "x")
+    m, k, ldx = _rows(x, "x")
+    if out_q is None:
+        out_q = torch.empty(m, k, dtype=FP8, device=x.device)
+    if out_scale is None:
+        out_scale = torch.empty(m, dtype=torch.float32, device=x.device)
+    assert out_q.dtype == FP8 and out_q.is_cuda and out_q.shape[-1] == k and out_q.stride(-1) == 1 and out_scale.numel() >= m
+    _lib.call("quant_rows_fp8", x, ldx, out_q, out_q.stride(-2) if out_q.dim() > 1 else k, out_scale, m, k)
+    return out_q, out_scale
+
+
+def gemm_fp8(a_q, a_scale, w_q, w_scale, bias=None, out=None, act: int = ACT_NONE, n_split: int = 0, out1=None,
+             act1: int = ACT_NONE, gate=None, res=None):
+    """out = (a_q @ w_q.T) * a_scale[:, None] * w_scale + bias with hv_gemm_bf16's epilogues; a_q [M,K], w_q [N,K] e4m3fn."""
+    for t, nm in ((a_q, "a_q"), (w_q, "w_q")):
+        if not t.is_cuda or t.dtype != FP8:
+            raise _lib.HVKernelError(f"gemm_fp8: {nm} must be a float8_e4m3fn GPU tensor")
+    _chk(a_scale, torch.float32, "a_scale"), _chk(w_scale, BF16, "w_scale")
+    m, k, lda = _rows(a_q, "a_q")
+    n, kw, ldw = _rows(w_q, "w_q")
+    assert k == kw and a_scale.numel() >= m and w_scale.numel() == 1
+    n0 = n_split if 0 < n_split < n else n
+    if out is None:
+        out = torch.empty(m, n0, dtype=BF16, device=a_q.device)
+    _chk(out, BF16, "out")
+    mo, no, ld0 = _rows(out, "out")
+    assert mo == m and no >= n0
+    ld1 = 0
+    if n0 < n:
+        _chk(out1, BF16, "out1")
+        m1, n1, ld1 = _rows(out1, "out1")
+        assert m1 == m and n1 >= n - n0
+    for t, nm in ((bias, "bias"), (gate, "gate")):
+        if t is not None:
+            _chk(t, BF16, nm)
+            assert t.numel() == n and t.is_contiguous()
+    ld_res = 0
+    if res is not None:
+        _chk(res, BF16, "res")
+        mr, nr, ld_res = _rows(res, "res")
+        assert mr == m and nr == n
+    _lib.call("gemm_fp8", a_q, lda, a_scale, w_q, ldw, w_scale, bias, m, n, k, out, ld0, act, n0, out1, ld1, act1, gate, res, ld_res)
+    return out
+
+
 def copy3d(src, dst, n_batch: int, rows: int, cols: int, src_bs: int, src_ld: int, dst_bs: int, dst_ld: int):
     """dst[b][r][:cols] = src[b][r][:cols] with explicit element strides; src/dst are any bf16 GPU tensors whose
     data_ptr() is element (0,0,0) of the region."""

@@ -127,6 +127,31 @@ int hv_copy3d_bf16(const void* src, void* dst, int n_batch, int64_t rows, int co
  * OCP e4m3fn (gfx950-native).  n % 8 == 0. */
 int hv_fp8_dequant_bf16(const void* w_e4m3fn, const void* scale_bf16, void* out_bf16, int64_t n, hipStream_t stream);
 
+/* ---- FP8-MFMA path (opt-in; BASELINE.json configs[3] "fp8 weight path (CDNA4 fp8 MFMA)").  The reference's FP8 is weight-only
+ * (fp8_optimization.py:50-80: e4m3fn weights + per-tensor `fp8_scale`, dequantised to bf16 every forward - that path is
+ * hv_fp8_dequant_bf16 + hv_gemm_bf16).  Here the SAME stored weights feed v_mfma_scale_f32_16x16x128_f8f6f4 directly and the
+ * activations are quantised per token: q = e4m3(clamp(x / s_row, +-448)), s_row = max|x_row| / 448, so
+ *   y[m][n] = (sum_k qa[m][k] * qw[n][k]) * s_row[m] * fp8_scale + bias[n]   followed by hv_gemm_bf16's epilogues.
+ * New error vs the reference path: the e4m3 rounding of the activations (2^-4 relative per element, averaging over K);
+ * tolerance stated in tests/test_gpu_fp8_mfma.py. */
+
+/* K1 with an fp8 output: y = bf16(LN(x) * bf16(1 + scale) + shift) (hv_ln_modulate_bf16 mode 0), then per-row quantisation:
+ * out_q [M, D] e4m3 bytes (row stride ldq bytes, % 16), out_row_scale [M] fp32. */
+int hv_ln_modulate_fp8(const void* x, const void* shift, const void* scale, void* out_q, float* out_row_scale, int64_t M,
+                       int D, int64_t ldx, int64_t ldq, float eps, hipStream_t stream);
+
+/* per-row quantisation of bf16 rows x[M, K] (row stride ldx elements) -> e4m3 rows + fp32 row scales (A operands that are not
+ * LayerNorm outputs: attention output, GELU(MLP) hidden, the single block's [attn | mlp] concat). */
+int hv_quant_rows_fp8(const void* x, int64_t ldx, void* out_q, int64_t ldq, float* out_row_scale, int64_t M, int K,
+                      hipStream_t stream);
+
+/* C = (A_q . W_q^T) * a_row_scale[m] * w_scale + bias with hv_gemm_bf16's epilogue arguments.  A_q [M, K], W_q [N, K]: e4m3fn
+ * bytes (row strides lda / ldw in bytes, % 16); w_scale_bf16: ONE bf16 on the device (the layer's `fp8_scale`).
+ * K % 128 == 0, K >= 384. */
+int hv_gemm_fp8(const void* A_q, int64_t lda, const float* a_row_scale, const void* W_q, int64_t ldw, const void* w_scale_bf16,
+                const void* bias, int M, int N, int K, void* out0, int64_t ld0, int act0, int n_split, void* out1, int64_t ld1,
+                int act1, const void* gate, const void* res, int64_t ld_res, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * 3D causal VAE decode (hyvideo/vae).  Activations are fp16, CHANNELS-LAST: row = voxel (t*H + h)*W + w, C contiguous.
  * --------------------------------------------------------------------------------------------------------- */

@@ -354,6 +354,40 @@ def denoise_loop(sd, cfg, latents: Tensor, n_steps: int, text_states, text_mask,
     return latents, preds
 
 
+# ----------------------------------------------------------------------------- FP8-MFMA path (quantisation-aware oracle)
+def fp8_quant_rows(x: Tensor) -> Tuple[Tensor, Tensor]:
+    """Per-token dynamic quantisation of a GEMM A operand on the opt-in FP8-MFMA path (include/hv_kernels.h, hv_quant_rows_fp8 /
+    hv_ln_modulate_fp8): s = max|x_row| * (1/448) (1 for an all-zero row), q = e4m3fn(clamp(x * (1/s), +-448)), round to nearest
+    even.  Not reference arithmetic (the reference's FP8 is weight-only, fp8_optimization.py:50-80): this states OUR contract so
+    that the kernels can be checked against it; the distance to the reference path is bounded separately in the tests."""
+    amax = x.abs().amax(dim=-1, keepdim=True).float()
+    s = torch.where(amax > 0, amax * torch.tensor(1.0 / 448.0, dtype=torch.float32), torch.ones_like(amax))
+    q = (x.float() * (1.0 / s)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    return q, s
+
+
+class Fp8MfmaPrec(Prec):
+    """bf16-emulated contract + FP8-MFMA Linears: a weight registered with `fp8(w8, scale)` is multiplied as
+    y = bf16( (Q(bf16(x)) . w8^T) * s_row * scale + b ); every other Linear follows Prec(True)."""
+
+    def __init__(self):
+        super().__init__(True)
+        self._fp8 = {}
+
+    def fp8(self, w8: Tensor, scale: Tensor) -> Tensor:
+        """returns the tensor to put into the state dict for this layer (the exact product w8 * scale)"""
+        w = w8.float() * scale.float()
+        self._fp8[id(w)] = True
+        return w
+
+    def linear(self, x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+        if id(w) not in self._fp8:
+            return super().linear(x, w, b)
+        q, s = fp8_quant_rows(self.r(x))
+        y = F.linear(q, w) * s
+        return self.r(y if b is None else y + self.r(b))
+
+
 # ----------------------------------------------------------------------------- FP8 weight-only path
 def fp8_maxval() -> float:
     """modules/fp8_optimization.py:7-18 (e4m3: 1.75 * 2^8)."""
