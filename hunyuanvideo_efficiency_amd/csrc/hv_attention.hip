@@ -884,7 +884,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
     // pin the accumulators under the full EXEC mask: the stores below sit in per-lane `row < n_q` regions and the compiler sinks
     // pure instructions towards their uses (see hv_gemm.hip: the last MFMAs must not end up inside a divergent region)
 #pragma unroll
-    for (int db = 0; db < 4; ++db) asm volatile("" : "+v"(oT[db]));
+    for (int db = 0; db < 4; ++db) asm volatile("" : : "v"(oT[db]));
 
     const float l_tot = half_swap_sum(l_run);
     if (a.n_splits > 1 || a.partial) {   // partial result: O^T unnormalised (fp32) + (m, l); merged by attn_combine_kernel

@@ -519,6 +519,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();                                     \
     __builtin_amdgcn_sched_barrier(0);                                \
     __builtin_amdgcn_s_setprio(1);
+#define HV_PHASE_SYNC_NOVM()                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_barrier();                                     \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_setprio(1);
 #define HV_PHASE_END()                                                \
     __builtin_amdgcn_s_setprio(0);                                    \
     __builtin_amdgcn_sched_barrier(0);                                \
@@ -529,6 +535,36 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     auto tile_fn = [&](auto BUFc, auto KINDc, int t) {
         constexpr int BUF = decltype(BUFc)::value, KIND = decltype(KINDc)::value;
         using B = std::integral_constant<int, BUF>;
+        if constexpr (DT::FP8) {
+            // fp8 schedule: ONE set of W fragments (8 registers each), B(n0) re-read in phase 4 (the 8-register operands leave no room
+            // to keep it: 28 instead of 24 fragment reads per K-tile).  The Bn0 slot then stays live until phase 4, so the DMA order
+            // is Am0(t+2), Bn1(t+2), Am1(t+2) in phases 2-4 and Bn0(t+1) in phase 1 of the NEXT... i.e. phase 1 issues Bn0 of
+            // tile t+1.  Everything tile t+1 needs is older than or equal to Bn0(t+1), which has exactly three younger half-tiles
+            // at the end of phase 4: one counted vmcnt(6) per K-tile covers all of it.
+            readB(B{}, I0{}, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            readA(B{}, I0{});
+            if constexpr (KIND <= 1) stage(I1{}, BUF ^ 1, t + 1);
+            HV_PHASE_SYNC_NOVM()
+            mma(I0{}, I0{}, wf0);
+            HV_PHASE_END()
+            readB(B{}, I1{}, wf0);
+            if constexpr (KIND == 0) stage(I0{}, BUF, t + 2);
+            HV_PHASE_SYNC_NOVM()
+            mma(I0{}, I1{}, wf0);
+            HV_PHASE_END()
+            readA(B{}, I1{});
+            if constexpr (KIND == 0) stage(I2{}, BUF, t + 2);
+            HV_PHASE_SYNC_NOVM()
+            mma(I1{}, I1{}, wf0);
+            HV_PHASE_END()
+            readB(B{}, I0{}, wf0);
+            if constexpr (KIND == 0) stage(I3{}, BUF, t + 2);
+            if constexpr (KIND == 0) { HV_PHASE_SYNC(6) } else { HV_PHASE_SYNC(0) }
+            mma(I1{}, I0{}, wf0);
+            HV_PHASE_END()
+            return;
+        }
         // phase 1: Q(m0, n0)
         readB(B{}, I0{}, wf0);
         __builtin_amdgcn_sched_barrier(0);
@@ -562,9 +598,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const int nkt = g.K * DT::ESIZE / (BK * 2);      // 128-byte K-tiles; >= 3 (host-side dispatch)
     const int ns = nkt - 2;        // steady tiles 0 .. nkt-3
     const int par = ns & 1;
-    stage(I0{}, par, 0); stage(I1{}, par, 0); stage(I2{}, par, 0); stage(I3{}, par, 0);
-    stage(I0{}, par ^ 1, 1); stage(I1{}, par ^ 1, 1); stage(I2{}, par ^ 1, 1);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if constexpr (DT::FP8) {     // issue order of the fp8 schedule: Am0, Bn1, Am1, Bn0 per K-tile; K-tile 0 complete = three younger half-tiles
+        stage(I0{}, par, 0); stage(I2{}, par, 0); stage(I3{}, par, 0); stage(I1{}, par, 0);
+        stage(I0{}, par ^ 1, 1); stage(I2{}, par ^ 1, 1); stage(I3{}, par ^ 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        stage(I0{}, par, 0); stage(I1{}, par, 0); stage(I2{}, par, 0); stage(I3{}, par, 0);
+        stage(I0{}, par ^ 1, 1); stage(I1{}, par ^ 1, 1); stage(I2{}, par ^ 1, 1);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();      // the second wave row runs one barrier interval behind the first
@@ -583,6 +625,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     tile_fn(I1{}, I2{}, t + 1);
     if (wm == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count of the staggered rows
 #undef HV_PHASE_SYNC
+#undef HV_PHASE_SYNC_NOVM
 #undef HV_PHASE_END
     // The epilogue's global reads (bias, gate, residual rows, fp8 row scales) must not be hoisted into the K loop's tail: every
     // wait there is a COUNTED vmcnt that assumes the only vector-memory operations in flight are the LDS-DMAs (an extra plain
@@ -596,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
+        for (int ni = 0; ni < 4; ++ni) asm volatile("" : : "v"(acc[mi][ni]));     // a USE, not a redefinition: no effect on the loop's allocation
     GemmArgs ge = g;
     asm volatile("s_waitcnt vmcnt(0)" : "+s"(ge.bias), "+s"(ge.gate), "+s"(ge.res), "+s"(ge.a_scale), "+s"(ge.w_scale), "+s"(ge.out0),
                  "+s"(ge.out1), "+s"(ge.out_f32) : : "memory");
