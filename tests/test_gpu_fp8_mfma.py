@@ -97,11 +97,12 @@ def test_gemm_fp8_random_vs_oracle_same_operands(ops, M, N, K):
     r_dev = res.to(DEV).clone()
     got = ops.gemm_fp8(aq, asc, w8.to(DEV), wscale.reshape(1).to(DEV), b.to(DEV), out=r_dev, gate=gate.to(DEV), res=r_dev)
     assert torch.equal(got.float().cpu(), R.gate_residual(res.float()[None], y[None], gate.float()[None], E)[0])
-    out0 = torch.zeros(M, N // 2 + 64, dtype=torch.bfloat16, device=DEV)
+    ns = (N // 2) // 8 * 8                  # column split (linear1's qkv | mlp): a multiple of 8
+    out0 = torch.zeros(M, ns + 64, dtype=torch.bfloat16, device=DEV)
     out1 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-    ops.gemm_fp8(aq, asc, w8.to(DEV), wscale.reshape(1).to(DEV), b.to(DEV), out=out0, n_split=N // 2, out1=out1[:, 8:])
-    assert torch.equal(out0[:, :N // 2].float().cpu(), y[:, :N // 2]) and torch.equal(out1[:, 8:8 + N - N // 2].float().cpu(), y[:, N // 2:])
-    assert float(out0[:, N // 2:].abs().max()) == 0 and float(out1[:, :8].abs().max()) == 0
+    ops.gemm_fp8(aq, asc, w8.to(DEV), wscale.reshape(1).to(DEV), b.to(DEV), out=out0, n_split=ns, out1=out1[:, 8:])
+    assert torch.equal(out0[:, :ns].float().cpu(), y[:, :ns]) and torch.equal(out1[:, 8:8 + N - ns].float().cpu(), y[:, ns:])
+    assert float(out0[:, ns:].abs().max()) == 0 and float(out1[:, :8].abs().max()) == 0
 
 
 def test_model_fp8_mfma_vs_quantisation_aware_oracle():
