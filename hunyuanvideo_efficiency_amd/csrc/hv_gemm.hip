@@ -397,7 +397,7 @@ constexpr int HT_BYTES = 16384;            // half-tile: 128 rows x 64 k x 2 B
 constexpr int BUF8_BYTES = 4 * HT_BYTES;   // [Am0 | Bn0 | Bn1 | Am1] of one K-tile
 constexpr int LDS8_BYTES = 2 * BUF8_BYTES; // 128 KiB
 
-template <typename DT>
+template <typename DT, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     typedef typename DT::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -426,14 +426,40 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int arow = i * 128 + h * 64 + srow;                       // tile row of LDS row (i*64 + srow) of half-tile Am<h>
+            if constexpr (CONV) {
+                // conv mode: row = output voxel.  Its (t, h, w) source coordinates (already multiplied by the stride) are kept PACKED
+                // in one register; the byte offset of the current tap's source row is re-formed from them only when the half-tile
+                // stream this row belongs to crosses into a new tap (every cin/64 K-tiles), see conv_tap().
+                const int ar = min(m0 + arow, g.M - 1);
+                const int vw = (ar % g.cW) * g.mw, th = ar / g.cW;
+                a_o[h][i] = (uint32_t)((th / g.cH) * g.mt) | ((uint32_t)((th % g.cH) * g.mh) << 8) | ((uint32_t)vw << 20);
+            } else
             a_o[h][i] = (uint32_t)((int64_t)(min(m0 + arow, g.M - 1) - m0) * g.lda * DT::ESIZE + ((scp ^ swz_a(srow)) << 4));
             const int lr = i * 64 + srow;                                   // LDS row of half-tile Bn<h>
             const int wrow = (lr >> 5) * 64 + h * 32 + (lr & 31);           // wave column (lr>>5), its W rows [h*32, h*32+32)
             w_o[h][i] = (uint32_t)((int64_t)(min(n0 + wrow, g.N - 1) - n0) * g.ldw * DT::ESIZE + ((scp ^ swz_w(lr)) << 4));
         }
     const int wave_lds = wave * 1024;
-    const char* a_tile = reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * DT::ESIZE;
+    const char* a_tile = CONV ? reinterpret_cast<const char*>(g.A) : reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * DT::ESIZE;
     const char* w_tile = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * DT::ESIZE;
+    // conv mode: byte offsets of the CURRENT tap's source rows, one set per A half-tile stream (Am0 and Am1 are staged in
+    // different phases for different K-tiles, so each stream crosses tap boundaries on its own)
+    uint32_t tap_off[2][2] = {{0u, 0u}, {0u, 0u}};
+    const uint32_t a_chunk = (uint32_t)((scp ^ swz_a(srow)) << 4);
+    const int lg_cin = CONV ? 31 - __builtin_clz((unsigned)g.cin) : 0;       // cin is a power of two >= 256 here (host-side dispatch)
+    auto conv_tap = [&](int h, int tap) {      // wave-uniform tap (dt, dh, dw): replicate / causal padding = the clamps, upsample = the halvings
+        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+        const uint32_t row_bytes = (uint32_t)g.lda * 2u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t c = a_o[h][i];
+            int ti = max((int)(c & 255u) + dt - 2, 0);
+            if (g.up_t) ti = ti == 0 ? 0 : 1 + ((ti - 1) >> 1);
+            const int hi = min(max((int)((c >> 8) & 4095u) + dh - 1, 0), g.bH - 1) >> g.up_hw;
+            const int wi = min(max((int)(c >> 20) + dw - 1, 0), g.bW - 1) >> g.up_hw;
+            tap_off[h][i] = (uint32_t)((ti * g.sH + hi) * g.sW + wi) * row_bytes + a_chunk;
+        }
+    };
 
     // half-tile J (0 Am0, 1 Bn0, 2 Bn1, 3 Am1) of K-tile `tile` into buffer `buf` (wave-uniform: the destination goes through M0)
     auto stage = [&](auto Jc, int buf, int tile) {
@@ -441,12 +467,19 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         char* dst = smem + buf * BUF8_BYTES + J * HT_BYTES + wave_lds;
         constexpr bool isA = (J == 0 || J == 3);
         constexpr int h = (J == 3 || J == 2) ? 1 : 0;
-        uint64_t bv = reinterpret_cast<uint64_t>((isA ? a_tile : w_tile) + (int64_t)tile * (BK * 2));
+        uint64_t bv;
+        if constexpr (CONV && isA) {
+            const int tap = (tile * BK) >> lg_cin, c0 = tile * BK - (tap << lg_cin);
+            if (c0 == 0) conv_tap(h, tap);       // a new tap for this stream: once per cin/64 K-tiles
+            bv = reinterpret_cast<uint64_t>(a_tile + c0 * 2);
+        } else {
+            bv = reinterpret_cast<uint64_t>((isA ? a_tile : w_tile) + (int64_t)tile * (BK * 2));
+        }
         asm volatile("" : "+s"(bv));
         const char* b = reinterpret_cast<const char*>(bv);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            uint32_t o = isA ? a_o[h][i] : w_o[h][i];
+            uint32_t o = isA ? (CONV ? tap_off[h][i] : a_o[h][i]) : w_o[h][i];
             asm volatile("" : "+v"(o));
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b + o), (lds_ptr_t)(dst + i * 8192), 16, 0, 0);
         }
@@ -647,13 +680,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     gemm_epilogue<DT, 256, 4>(ge, acc, m0, n0, wm, wn, fr, fq);
 }
 
-template <typename DT>
+template <typename DT, bool CONV = false>
 int launch_gemm8(GemmArgs& g, hipStream_t stream) {
     static HvPerDeviceOnce once;
-    if (hv_set_max_lds(once, (const void*)gemm8_kernel<DT>, LDS8_BYTES) != HV_OK) return HV_ERR_LAUNCH;
+    if (hv_set_max_lds(once, (const void*)gemm8_kernel<DT, CONV>, LDS8_BYTES) != HV_OK) return HV_ERR_LAUNCH;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + 255) / 256;
-    gemm8_kernel<DT><<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS8_BYTES, stream>>>(g);
+    gemm8_kernel<DT, CONV><<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS8_BYTES, stream>>>(g);
     return hv_check_launch();
 }
 
@@ -674,6 +707,13 @@ int launch(GemmArgs& g, hipStream_t stream) {
     if (g.N <= 128) return launch_bn<DT, CONV, 128>(g, stream);
     if constexpr (!CONV) {
         if (g.K >= 3 * BK && !hv_gemm_force_2stage()) return launch_gemm8<DT>(g, stream);     // pipelined main loop
+    } else if constexpr (std::is_same<DT, F16T>::value) {
+        // conv: the pipelined loop re-forms its gather offsets per tap from packed coordinates (no room for the 36 separable offsets
+        // next to the deeper pipeline's fragments), which pays when a tap spans >= 4 K-tiles: cin a power of two >= 256 - the 256-
+        // and 512-channel layers that make up the BN = 256 convs of the decoder; coordinates must fit the packing (t < 256, h, w < 4096)
+        const bool pow2 = (g.cin & (g.cin - 1)) == 0;
+        if (pow2 && g.cin >= 256 && g.cT * g.mt < 256 && g.bH <= 4096 && g.bW <= 4096 && !hv_gemm_force_2stage())
+            return launch_gemm8<DT, true>(g, stream);
     }
     return launch_bn<DT, CONV, 256>(g, stream);
 }
