@@ -71,6 +71,7 @@ class UlyssesLongContextAttention:
 
     _default_group = None
     _default_ring_group = None
+    MIN_SEG_ROWS = 256       # attend_async: no segment of the output exchange smaller than one GEMM tile of rows (tests lower it)
 
     def __init__(self, group=None, kernels=None, ring_group=None):
         self.group = group if group is not None else UlyssesLongContextAttention._default_group
@@ -78,6 +79,7 @@ class UlyssesLongContextAttention:
         self.k = kernels or _HipKernels
         self._bufs = {}
         self._parts = None
+        self.min_seg_rows = UlyssesLongContextAttention.MIN_SEG_ROWS
 
     @classmethod
     def set_sequence_parallel_group(cls, group, ring_group=None):
@@ -200,20 +202,76 @@ class UlyssesLongContextAttention:
             self.k.copy3d(joint[:, rank * w:], full[P * s_loc:], 1, n_j, w, 0, ld_j, 0, w)
 
     def attend(self, out: torch.Tensor, ld_out: int):
+        """Synchronous form: attention + output exchange + unpack of every row into `out` before returning."""
+        for _, _, finish in self.attend_async(out, ld_out, nseg=1):
+            finish()
+
+    def attend_async(self, out: torch.Tensor, ld_out: int, nseg: int = 2):
+        """Attention over all tokens for this rank's heads, then the OUTPUT exchange cut into `nseg` row segments of the local
+        image tokens so that it overlaps the out-projection GEMM that consumes it (north_star: "all-to-all ... overlapped with the
+        per-head GEMMs"): every segment is its own asynchronous exchange (started at once, RCCL runs them on its stream in order);
+        the caller walks the returned [(row_lo, row_hi, finish)] list - finish() makes the compute stream wait for THAT segment
+        and unpacks it into out[row_lo:row_hi] - and launches the GEMM of those rows while the next segment is still on the wire.
+        The last segment also covers the joint (text) rows [s_loc, s_loc + n_j).
+        A segment of rows [r0, r1) is, per peer p, the contiguous slice of[p*s_loc + r0 : p*s_loc + r1] -> recv[p][r0:r1]: one
+        point-to-point pair per peer (`batch_isend_irecv`, coalesced by RCCL into one grouped launch = an all-to-all of that
+        segment; every xGMI link carries exactly its pair's bytes)."""
         P, rank, s_loc, n_j, heads, w = self._geo
         for wk in self._works:
-            wk.wait()                       # the compute stream waits for the exchanges (no host sync)
+            wk.wait()                       # the compute stream waits for the q/k/v exchanges (no host sync)
         self._works = []
         b = self._bufs
         s_img = P * s_loc
         self._attention(b, heads // P, s_img, n_j)
+        of = b["of"]
         recv = self._buf("recv", (s_img, w), out.device)
-        dist.all_to_all_single(recv, b["of"][:s_img], group=self.group)
-        self.k.copy3d(recv, out, P, s_loc, w, s_loc * w, w, w, ld_out)
+        nseg = max(1, min(nseg, s_loc // self.min_seg_rows))
+        bounds = [((s_loc * i) // nseg) for i in range(nseg + 1)]
+        seg_works = []
+        for r0, r1 in zip(bounds[:-1], bounds[1:]):
+            if P == 1:
+                seg_works.append([])
+                continue
+            if r0 == 0 and r1 == s_loc:
+                seg_works.append([dist.all_to_all_single(recv, of[:s_img], group=self.group, async_op=True)])
+                continue
+            p2p = []
+            for p in range(P):
+                if p == rank:
+                    continue
+                peer = dist.get_global_rank(self.group, p) if self.group is not None else p
+                p2p.append(dist.P2POp(dist.isend, of[p * s_loc + r0:p * s_loc + r1], peer, self.group))
+                p2p.append(dist.P2POp(dist.irecv, recv[p * s_loc + r0:p * s_loc + r1], peer, self.group))
+            seg_works.append(dist.batch_isend_irecv(p2p))
+        txt_work = None
         if n_j:
             recv_t = self._buf("recv_t", (P * n_j, w), out.device)
-            dist.all_gather_into_tensor(recv_t, b["of"][s_img:].contiguous(), group=self.group)
-            self.k.copy3d(recv_t, out[s_loc:], P, n_j, w, n_j * w, w, w, ld_out)
+            txt_work = dist.all_gather_into_tensor(recv_t, of[s_img:].contiguous(), group=self.group, async_op=True)
+
+        def make_finish(r0, r1, works, last):
+            def finish():
+                for wk in works:
+                    wk.wait()
+                if P == 1 or not (r0 == 0 and r1 == s_loc):
+                    # this rank's own slice never crosses a link: it is unpacked straight from the attention output
+                    self.k.copy3d(of[rank * s_loc + r0:], out[r0:, rank * w:], 1, r1 - r0, w, 0, w, 0, ld_out)
+                    if P > 1:
+                        for p in range(P):
+                            if p != rank:
+                                self.k.copy3d(recv[p * s_loc + r0:], out[r0:, p * w:], 1, r1 - r0, w, 0, w, 0, ld_out)
+                else:
+                    # unpack: out[r][p*w + c] = recv[p][r][c]
+                    self.k.copy3d(recv, out, P, s_loc, w, s_loc * w, w, w, ld_out)
+                if last and n_j:
+                    txt_work.wait()
+                    self.k.copy3d(recv_t, out[s_loc:], P, n_j, w, n_j * w, w, w, ld_out)
+            return finish
+
+        segs = []
+        for i, ((r0, r1), works) in enumerate(zip(zip(bounds[:-1], bounds[1:]), seg_works)):
+            last = i == len(seg_works) - 1
+            segs.append((r0, (s_loc + n_j) if last else r1, make_finish(r0, r1, works, last)))
+        return segs
 
     # ------------------------------------------------------------------ reference hook signature
     def __call__(self, attn, query, key, value, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),

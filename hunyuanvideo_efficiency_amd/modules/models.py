@@ -164,8 +164,10 @@ class MMDoubleStreamBlock(nn.Module):
             else:
                 _gemm(ws, qkv_l, "xmod", lo, hi, fp8[s], out=ws.qkv[lo:hi])
                 ops.qknorm_rope_(ws.qkv[lo:hi], qw, kw, cos, sin, n_rope, H, d)
+        segs = None
         if overlap:
-            sp.attend(ws.cat, ws.cat.stride(0))
+            # the output exchange travels in row segments: segment i+1 is on the wire while the out-projection of segment i runs
+            segs = sp.attend_async(ws.cat, ws.cat.stride(0))
             pad_segment_attention_(ws.qkv, ws.cat, cu1, H, d)
         else:
             segment_attention_(sp, ws.qkv, ws.cat, s_img, cu1, H, d)
@@ -174,7 +176,13 @@ class MMDoubleStreamBlock(nn.Module):
             _, _, g1, sh2, sc2, g2 = mods[s]
             proj, mlp = getattr(self, f"{s}_attn_proj"), getattr(self, f"{s}_mlp")
             x = ws.x[lo:hi]
-            _gemm(ws, proj, "attn", lo, hi, fp8[s], out=x, gate=g1, res=x)
+            if s == "img" and segs is not None:
+                for r0, r1, finish in segs:
+                    finish()
+                    r1 = min(r1, hi)
+                    _gemm(ws, proj, "attn", r0, r1, fp8[s], out=ws.x[r0:r1], gate=g1, res=ws.x[r0:r1])
+            else:
+                _gemm(ws, proj, "attn", lo, hi, fp8[s], out=x, gate=g1, res=x)
             _ln(ws, lo, hi, sh2, sc2, fp8[s])
             _gemm(ws, mlp.fc1, "xmod", lo, hi, fp8[s], out=ws.cat[lo:hi, d:], act=ops.ACT_GELU_TANH)
             _gemm(ws, mlp.fc2, "hid", lo, hi, fp8[s], out=x, gate=g2, res=x)
@@ -240,8 +248,14 @@ class MMSingleStreamBlock(nn.Module):
             ops.qknorm_rope_(ws.qkv[s_img:], self.q_norm.weight, self.k_norm.weight, None, None, 0, H, d)
             _sp_chunked_qkv(sp, ws, self.linear1, fp8, self.q_norm.weight, self.k_norm.weight, cos, sin, s_img, cu1, n_rope, H, d)
             _gemm(ws, self.linear1, "xmod", 0, s_all, fp8, wrows=slice(3 * d, None), out=ws.cat[:, d:], act=ops.ACT_GELU_TANH)
-            sp.attend(ws.cat, ws.cat.stride(0))
+            segs = sp.attend_async(ws.cat, ws.cat.stride(0))
             pad_segment_attention_(ws.qkv, ws.cat, cu1, H, d)
+            # linear2 by row segments as their attention columns arrive (the last one takes the text rows, valid and padding)
+            for i, (r0, r1, finish) in enumerate(segs):
+                finish()
+                r1 = s_all if i == len(segs) - 1 else r1
+                _gemm(ws, self.linear2, "cat", r0, r1, fp8, out=ws.x[r0:r1], gate=gate, res=ws.x[r0:r1])
+            return
         else:
             # linear1: cols [0,3d) -> qkv ; cols [3d, 3d+mlp) -> GELU-tanh -> cat[:, d:]   (models.py:339-341,392)
             _gemm(ws, self.linear1, "xmod", 0, s_all, fp8, out=ws.qkv, n_split=3 * d, out1=ws.cat[:, d:], act1=ops.ACT_GELU_TANH)

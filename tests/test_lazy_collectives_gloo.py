@@ -119,6 +119,21 @@ def _worker(rank, world, port, U, R, results):
             sp.attend(cat, d + 64)
             assert bool(torch.isfinite(cat.float()).all()), "a collective's output was consumed before wait()"
             torch.testing.assert_close(cat[:, :d].float(), exp.reshape(-1, d), **TOL)
+        # segmented output exchange (attend_async): three row segments, each an asynchronous point-to-point group; a segment's
+        # rows may only be read after ITS finish() - read the segments in order and check the rows not yet finished are untouched
+        sp.min_seg_rows = 16
+        cat = torch.full((rows, d + 64), 7.0, dtype=torch.bfloat16)
+        sp.begin(s_loc, n_txt, H, qkv.device)
+        for i, nm in enumerate("qkv"):
+            sp.send(nm, qkv[:, i * d:], 3 * d, qkv[s_loc:, i * d:], 3 * d)
+        segs = sp.attend_async(cat, d + 64, nseg=3)
+        assert len(segs) == 3 and segs[0][0] == 0 and segs[-1][1] == rows
+        for r0, r1, finish in segs:
+            assert float((cat[r0:r1, :d].float() - 7.0).abs().max()) == 0, "rows written before their segment finished"
+            finish()
+            torch.testing.assert_close(cat[r0:r1, :d].float(), exp.reshape(-1, d)[r0:r1], **TOL)
+        assert float((cat[:, d:].float() - 7.0).abs().max()) == 0
+        sp.min_seg_rows = 256
         # the reference hook signature goes through the same machinery
         out = sp(None, q[:, sl], k[:, sl], v[:, sl], joint_tensor_query=q[:, s_img:], joint_tensor_key=k[:, s_img:],
                  joint_tensor_value=v[:, s_img:], joint_strategy="rear")

@@ -65,6 +65,8 @@ def _worker(rank, world, port, results):
         from tests import cpu_kernel_doubles as D
         from tests.test_ulysses_gloo import CpuKernelDouble
         from hunyuanvideo_efficiency_amd.inference import parallelize_transformer_module
+        from hunyuanvideo_efficiency_amd.long_ctx_attention import UlyssesLongContextAttention
+        UlyssesLongContextAttention.MIN_SEG_ROWS = 8     # toy shards: still cut the output exchange into two row segments
         D.install()
         cfg, model = _build_cpu_model()
         for thw in ((5, 16, 16), (3, 12, 16)):        # (H/2) % 2 == 0 -> split along H; (H/2) = 6 also even -> H again
