@@ -158,6 +158,13 @@ def main():
         # cold shell: become the launcher (before torch is imported; this process never touches the GPU)
         raise SystemExit(launch_ranks(a.gpus))
 
+    # Only the ONE JSON line may reach stdout: RCCL prints a version banner to stdout when its first communicator is created
+    # (and libraries may log there too), so this process keeps a private handle on the real stdout for the result line and
+    # points fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -306,7 +313,8 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(f_step)
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if world > 1 or a.force_sp:
         dist.barrier()
         dist.destroy_process_group()
