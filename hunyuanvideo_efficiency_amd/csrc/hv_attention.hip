@@ -922,6 +922,357 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
 }
 
 
+// =====================================================================================================================
+// v5 = v4 with the per-tile barrier moved two MFMA gaps before the end of the iteration (see gap 30 in body_main): the next
+// tile's LDS-DMA issue and its first K fragment reads ride under the last two MFMAs.
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | V0 | V1], 16 KiB each
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.x / a.n_qtiles;
+    const int qt = blockIdx.x % a.n_qtiles;
+    if (a.n_splits > 1) {   // this workgroup's key range
+        const int kv0 = blockIdx.y * a.split_keys;
+        a.k += (int64_t)kv0 * a.sk;
+        a.v += (int64_t)kv0 * a.sv;
+        a.n_kv = min(a.n_kv - kv0, a.split_keys);
+    }
+    const int q0 = qt * QTILE + wave * QROWS_WAVE;
+    constexpr int KOFF = 0, VOFF = 2 * KV_TILE_BYTES;
+
+    bf16x8 qf[8];
+    {
+        const int qrow = min(q0 + lr, a.n_q - 1);
+        const bf16_t* qp = a.q + (int64_t)qrow * a.sq + head * D + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            // Q' = bf16(Q * scale * log2(e)): the scores leave the MFMA already in the exp2 domain (one rounding of q, 2^-9 relative)
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+            u32x4 sc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[j] = pack_bf2(bf2f_lo(raw[j]) * a.scale_log2e, bf2f_hi(raw[j]) * a.scale_log2e);
+            qf[ks] = __builtin_bit_cast(bf16x8, sc);
+        }
+    }
+
+    // ---- DMA addressing: wave w owns keys [8w, 8w+8) of a tile; piece i (0,1): key = 8w + 4i + (lane>>4), LDS chunk pos = lane&15.
+    // LDS-DMA by buffer_load ... lds: the descriptor (4 SGPRs, rebuilt per tile by scalar arithmetic) starts at the tile and covers
+    // exactly its valid rows, the per-lane byte offset never changes.  Keys past n_kv in a ragged last tile fall outside the
+    // descriptor: the hardware range check returns zeros for them - no clamped copies of the offsets (4 VGPRs), no selects; those
+    // keys are masked to -inf after the S MFMAs as before.
+    const char* kbase = reinterpret_cast<const char*>(a.k + head * D);
+    const char* vbase = reinterpret_cast<const char*>(a.v + head * D);
+    uint32_t koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = 8 * wave + (lane >> 4) + 4 * i, dcp = lane & 15;
+        koff[i] = (uint32_t)(key * (int)a.sk * 2 + ((dcp ^ (key & 15)) << 4));
+        voff[i] = (uint32_t)(key * (int)a.sv * 2 + ((dcp ^ ((key & 3) << 2)) << 4));
+    }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 2048;   // 8 keys x 256 B; scalar: the DMA destination goes through M0
+    const int64_t k_tile_bytes = (int64_t)KVT * a.sk * 2, v_tile_bytes = (int64_t)KVT * a.sv * 2;
+    auto dma_tile = [&](const char* base, int64_t tile_bytes, int row_bytes, const uint32_t (&off)[2], int tile, int lds_base) {
+        const int rows = min(a.n_kv - tile * KVT, KVT);
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + tile * tile_bytes), 0, rows * row_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(smem + lds_base + wave_lds + i * 1024), 16, off[i], 0, 0, 0);
+    };
+    auto dma_k = [&](int tile, int buf) { dma_tile(kbase, k_tile_bytes, (int)a.sk * 2, koff, tile, KOFF + buf * KV_TILE_BYTES); };
+    auto dma_v = [&](int tile, int buf) { dma_tile(vbase, v_tile_bytes, (int)a.sv * 2, voff, tile, VOFF + buf * KV_TILE_BYTES); };
+
+    int kread[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = kb * 32 + lr;
+        kread[kb] = key * 256 + ((lh ^ (key & 15)) << 4);
+    }
+    const int vq = (lane & 15) >> 2, vp = lane & 3, vG = lane >> 4;
+    int vread;
+    {
+        const int key = 4 * (vG >> 1) + vq;
+        const int chunk16 = ((vG & 1) * 16 + 4 * vp) >> 3;
+        vread = key * 256 + ((chunk16 ^ ((key & 3) << 2)) << 4) + (vp & 1) * 8;
+    }
+
+    f32x16 oT[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oT[db][r] = 0.f;
+    // m_run: the row max the running sums are scaled by (log2 domain).  It is DEFERRED: it only moves when a tile's scores exceed
+    // it by more than THR, so P <= 2^THR instead of <= 1 (bf16 and fp32 keep their relative precision at any scale).  -m_run sits
+    // in all 16 registers of `negm`, the C operand of the first MFMA of every S chain: S' = K.Q'^T - m_run comes out of the matrix
+    // pipe ready for exp2 - no scale/subtract pass on the VALU at all.
+    float m_run = 0.f, l_run = 0.f;
+    f32x16 negm;
+    bf16x8 fr[4];      // 4-slot K/V fragment ring (gap g uses slot g % 4, loaded two gaps ahead; 32 gaps per tile keep the slots aligned)
+    constexpr float THR = 8.0f;
+    const int ntiles = (a.n_kv + KVT - 1) / KVT;
+
+    auto qk = [&](f32x16 (&S)[2], int buf, const f32x16& c0) {
+        const char* kb_ = smem + KOFF + buf * KV_TILE_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_ + (kread[kb] ^ (ks << 5)));
+                S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? c0 : S[kb], 0, 0, 0);
+            }
+        }
+    };
+    auto exp_block = [&](const f32x16& S, bf16x8 (&pf)[2], float& ls) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(S[8 * s + j]);
+                const float p1 = __builtin_amdgcn_exp2f(S[8 * s + j + 1]);
+                ls += p0;      // ONE serial chain of plain v_add_f32: (p0 + p1) pairs would be SLP-packed into v_pk_add_f32, which
+                ls += p1;      // beside MFMAs costs more than it saves
+                w[j >> 1] = pack_bf2(p0, p1);
+            }
+            pf[s] = __builtin_bit_cast(bf16x8, w);
+        }
+    };
+    auto pv_block = [&](const bf16x8 (&pf)[2], int kb, int buf) {
+        const char* vb_ = smem + VOFF + buf * KV_TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int koff = (kb * 32 + 16 * s) * 256;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const char* p0 = vb_ + ((vread + koff) ^ (db << 6));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * 256));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oT[db], 0, 0, 0);
+            }
+        }
+    };
+    // tail mask (last tile) + row max of a score tile (relative to m_run); VALU only, placed under the P.V MFMAs of the tile before
+    auto tile_max = [&](f32x16 (&Sc)[2], int t, bool last) -> float {
+        if (last && (a.n_kv & (KVT - 1))) {
+            const int kbase_i = t * KVT + 4 * lh;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase_i + kb * 32 + (r & 3) + 8 * (r >> 2);
+                    if (key >= a.n_kv) Sc[kb][r] = -INFINITY;
+                }
+        }
+        float mx = Sc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, Sc[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, Sc[1][r]);
+        return half_swap_max(mx);
+    };
+    // rare: some row of this tile exceeds the running max by more than THR -> move every row's max to its true value, rescale
+    // the sums, the scores of THIS tile (already relative to the old max) and the C operand of the next S chain
+    auto raise_max = [&](f32x16 (&Sc)[2], float mx) {
+        const float d = fmaxf(mx, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        l_run *= alpha;
+        m_run += d;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oT[db][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Sc[kb][r] -= d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+        asm volatile("" : "+v"(negm));      // 16 live registers, not 16 re-materialised moves per tile
+    };
+    // steady-state iteration: consumes Sc = S'(t) and its row max mx_c, produces Sn = S'(t+1) and mx_n.
+    // The 32 MFMAs of a tile are laid out as 32 "gaps" in SOURCE order, each closed by a scheduling fence, so that every MFMA is
+    // followed by its share of the tile's VALU and LDS work (guide: <= 5 single-issue fillers per 32-cycle MFMA, at most one or two
+    // of them an 8-cycle v_exp_f32) instead of the compiler's front-loaded order (all exps under the first seven MFMAs):
+    //   gaps  0-15  S'(t+1) chain (K fragments 2 gaps ahead) | exp/pack of P block 0, element g; of block 1, element g/2 (even g)
+    //   gaps 16-23  O += V.P block 0 (V fragments 2 ahead)    | exp/pack of P block 1, elements 8..15
+    //   gaps 24-31  O += V.P block 1                          | row max of S'(t+1), 4 values per gap
+    // NEXT_LAST: tile t+1 may be the (possibly ragged) last one - its masked row max is taken after the gaps instead.
+    auto body_main = [&](f32x16 (&Sc)[2], f32x16 (&Sn)[2], int t, float mx_c, float& mx_n, auto next_last_c) {
+        constexpr bool NEXT_LAST = decltype(next_last_c)::value;
+        // on entry: fr[0], fr[1] hold K(t+1) fragments 0 and 1; the DMAs of K(t+2) and V(t+1) are in flight
+        if (__any(mx_c > THR)) raise_max(Sc, mx_c);
+        const char* kb_ = smem + KOFF + ((t + 1) & 1) * KV_TILE_BYTES;
+        const char* vb_ = smem + VOFF + (t & 1) * KV_TILE_BYTES;
+        auto kload = [&](int i) { return *reinterpret_cast<const bf16x8*>(kb_ + (kread[i >> 3] ^ ((i & 7) << 5))); };
+        auto vload = [&](int j) {      // j = (kb*2 + s)*4 + db
+            const int koff_ = ((j >> 3) * 32 + 16 * ((j >> 2) & 1)) * 256;
+            const char* p0 = vb_ + ((vread + koff_) ^ ((j & 3) << 6));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * 256));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        const char* kn_ = smem + KOFF + (t & 1) * KV_TILE_BYTES;      // K(t+2) will land where K(t) was
+        auto knext = [&](int i) { return *reinterpret_cast<const bf16x8*>(kn_ + (kread[i >> 3] ^ ((i & 7) << 5))); };
+        u32x4 w0[2], w1[2];
+        float P0[16], P1[16];          // this tile's exponentials (compile-time indices: registers, each live for about one gap)
+        float ls = 0.f, mxa = -INFINITY, mxb = -INFINITY;
+        // row sum: one pinned v_add_f32 per value, issued ONE GAP AFTER its v_exp_f32 (a pure `ls += p` chain is emitted as 32
+        // dependent adds after the last gap with all 32 values held live; pinned in the exp's own gap an asm add could sit in the
+        // trans->VALU forwarding slot, which the compiler only pads for instructions it can see)
+        auto acc = [&](float p) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls) : "v"(p)); };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            if (g < 16) {
+                if (g + 2 < 16) fr[(g + 2) % 4] = kload(g + 2);
+                else fr[(g + 2) % 4] = vload(g - 14);
+                if (g >= 1) {
+                    acc(P0[g - 1]);
+                    if (!((g - 1) & 1)) acc(P1[(g - 1) >> 1]);
+                }
+                Sn[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 4], qf[g & 7], (g & 7) == 0 ? negm : Sn[g >> 3], 0, 0, 0);
+                P0[g] = __builtin_amdgcn_exp2f(Sc[0][g]);
+                if (g & 1) w0[g >> 3][(g & 7) >> 1] = pack_bf2(P0[g - 1], P0[g]);
+                if (!(g & 1)) {
+                    const int e = g >> 1;
+                    P1[e] = __builtin_amdgcn_exp2f(Sc[1][e]);
+                    if (e & 1) w1[0][(e & 7) >> 1] = pack_bf2(P1[e - 1], P1[e]);
+                }
+            } else {
+                const int j = g - 16;
+                if (g == 30) {
+                    // the tile's one barrier sits HERE, two MFMAs before the end: every LDS read of this iteration has been issued
+                    // (the last V fragments at gap 29), the DMAs started a whole iteration ago have long landed, so the next
+                    // iteration's DMAs and its first two K fragment reads go under the last two MFMAs instead of in front of an
+                    // idle matrix pipe after the barrier (8 waves x ~150 cycles of LDS latency + ~30 scalar instructions per tile)
+                    __syncthreads();
+                    if (t + 3 < ntiles) dma_k(t + 3, (t + 1) & 1);
+                    if (t + 2 < ntiles) dma_v(t + 2, t & 1);
+                }
+                if (j + 2 < 16) fr[(g + 2) % 4] = vload(j + 2);
+                else if (t + 2 < ntiles) fr[(g + 2) % 4] = knext(g - 30);      // gaps 30, 31 -> K(t+2) fragments 0, 1 (slots 0, 1)
+                if (j == 0) acc(P0[15]);
+                if (j >= 1 && j <= 8) acc(P1[7 + j]);
+                const int s_ = (j >> 2) & 1, db = j & 3;
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, j < 8 ? w0[s_] : w1[s_]);
+                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 4], pf, oT[db], 0, 0, 0);
+                if (j < 8) {
+                    const int e = 8 + j;
+                    P1[e] = __builtin_amdgcn_exp2f(Sc[1][e]);
+                    if (e & 1) w1[1][(e & 7) >> 1] = pack_bf2(P1[e - 1], P1[e]);
+                } else if (!NEXT_LAST) {
+                    const int q4 = (j - 8) * 4;            // values q4 .. q4+3 of the 32 scores per lane
+                    // v_max3_f32 by hand, volatile: (a) fmaxf() on MFMA results costs two canonicalising v_max each, (b) a pure
+                    // expression is emitted next to its only consumer after the last gap; the fences pin a volatile asm to ITS gap.
+                    // Operands: S'(t+1) registers whose MFMA chains retired >= 8 gaps (> 256 cycles) ago - no MFMA->VALU hazard.
+                    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mxa) : "v"(Sn[q4 >> 4][q4 & 15]), "v"(Sn[q4 >> 4][(q4 & 15) + 1]));
+                    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mxb) : "v"(Sn[q4 >> 4][(q4 & 15) + 2]), "v"(Sn[q4 >> 4][(q4 & 15) + 3]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (NEXT_LAST) mx_n = tile_max(Sn, t + 1, t + 2 == ntiles);
+        else mx_n = half_swap_max(fmaxf(mxa, mxb));
+        l_run += ls;
+    };
+    auto body_last = [&](f32x16 (&Sc)[2], int t, float mx_c) {
+        if (__any(mx_c > THR)) raise_max(Sc, mx_c);
+        bf16x8 p0[2], p1[2];
+        float ls = 0.f;
+        exp_block(Sc[0], p0, ls);
+        pv_block(p0, 0, t & 1);
+        exp_block(Sc[1], p1, ls);
+        pv_block(p1, 1, t & 1);
+        l_run += ls;
+    };
+
+    f32x16 sA[2], sB[2];
+    dma_k(0, 0);
+    dma_v(0, 0);
+    if (ntiles > 1) dma_k(1, 1);
+    __syncthreads();
+    {
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        qk(sA, 0, zero);
+    }
+    // tile 0 fixes the initial max exactly: m_run = rowmax(S(0)), S'(0) = S(0) - m_run (the only explicit subtraction)
+    m_run = tile_max(sA, 0, ntiles == 1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sA[kb][r] -= m_run;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+    asm volatile("" : "+v"(negm));
+    __syncthreads();   // every wave finished reading K[0] before tile 2 is DMA'd over it
+    // entry state of the first iteration: DMAs of K(2) and V(1) in flight, K(1) fragments 0 and 1 in fr[0], fr[1]
+    if (ntiles > 2) dma_k(2, 0);
+    if (ntiles > 1) {
+        dma_v(1, 1);
+        const char* k1_ = smem + KOFF + KV_TILE_BYTES;
+        fr[0] = *reinterpret_cast<const bf16x8*>(k1_ + kread[0]);
+        fr[1] = *reinterpret_cast<const bf16x8*>(k1_ + (kread[0] ^ (1 << 5)));
+    }
+    int t = 0;
+    float mxA = 0.f, mxB = 0.f;
+    // inside the loop neither call may PRODUCE the last tile (t+1 and t+2 <= ntiles-2): no mask code there, the row max rides
+    // under the P.V MFMAs; the 1-3 tiles left over take the masked variant for the call that produces the last tile
+    for (; t + 3 < ntiles; t += 2) {
+        body_main(sA, sB, t, mxA, mxB, std::false_type{});
+        body_main(sB, sA, t + 1, mxB, mxA, std::false_type{});
+    }
+    // the 0-2 iterations left before the final tile: ONE more instance of the body (row max after the gaps, tail mask when the
+    // tile it produces is the last), scores handed back through a register copy instead of a second unrolled name swap
+    for (; t + 1 < ntiles; ++t) {
+        body_main(sA, sB, t, mxA, mxB, std::true_type{});
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sA[kb] = sB[kb];
+        mxA = mxB;
+    }
+    body_last(sA, t, mxA);
+    // pin the accumulators under the full EXEC mask: the stores below sit in per-lane `row < n_q` regions and the compiler sinks
+    // pure instructions towards their uses (see hv_gemm.hip: the last MFMAs must not end up inside a divergent region)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) asm volatile("" : : "v"(oT[db]));
+
+    const float l_tot = half_swap_sum(l_run);
+    if (a.n_splits > 1 || a.partial) {   // partial result: O^T unnormalised (fp32) + (m, l); merged by attn_combine_kernel
+        const int qrow_p = q0 + lr;
+        if (qrow_p < a.n_q) {
+            const int64_t rowi = ((int64_t)blockIdx.y * a.n_q + qrow_p) * a.n_heads + head;
+            float* po = a.part_o + rowi * D + 4 * lh;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(po + db * 32 + g * 8) =
+                        make_float4(oT[db][4 * g], oT[db][4 * g + 1], oT[db][4 * g + 2], oT[db][4 * g + 3]);
+            if (lh == 0) {
+                a.part_ml[rowi * 2] = m_run;
+                a.part_ml[rowi * 2 + 1] = l_tot;
+            }
+        }
+        return;
+    }
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + lr;
+    if (qrow < a.n_q) {
+        bf16_t* op = a.o + (int64_t)qrow * a.so + head * D + 4 * lh;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w[0] = pack_bf2(oT[db][4 * g] * inv, oT[db][4 * g + 1] * inv);
+                w[1] = pack_bf2(oT[db][4 * g + 2] * inv, oT[db][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(op + db * 32 + g * 8) = w;
+            }
+    }
+}
+
+
 // merge the KV-split partials: O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m),  m = max_s m_s  (log2 domain)
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                             bf16_t* __restrict__ o, int64_t so, int n_q, int n_heads, int n_splits) {
@@ -950,14 +1301,14 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     *reinterpret_cast<u32x2*>(o + row * so + head * D + d4 * 4) = w2;
 }
 
-HvPerDeviceOnce g_attn_lds_once, g_attn3_lds_once, g_attn4_lds_once;
+HvPerDeviceOnce g_attn_lds_once, g_attn3_lds_once, g_attn4_lds_once, g_attn5_lds_once;
 
 // HV_ATTN_V2=1 / HV_ATTN_VER=2|3: keep a previous kernel (same-box A/B, tests/test_gpu_attention_v3.py); read per call
 inline int attn_ver() {
     const char* e2 = std::getenv("HV_ATTN_V2");
     if (e2 && e2[0] == '1') return 2;
     const char* e = std::getenv("HV_ATTN_VER");
-    return e && e[0] >= '2' && e[0] <= '4' ? e[0] - '0' : 4;
+    return e && e[0] >= '2' && e[0] <= '5' ? e[0] - '0' : 5;
 }
 
 int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
@@ -965,6 +1316,9 @@ int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
     if (ver == 2) {
         if (hv_set_max_lds(g_attn_lds_once, (const void*)attn_fwd_kernel_v2, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
         attn_fwd_kernel_v2<<<grid, dim3(512), ATT_LDS, stream>>>(a);
+    } else if (ver == 5) {
+        if (hv_set_max_lds(g_attn5_lds_once, (const void*)attn_fwd_kernel_v5, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
+        attn_fwd_kernel_v5<<<grid, dim3(512), ATT_LDS, stream>>>(a);
     } else if (ver == 4) {
         if (hv_set_max_lds(g_attn4_lds_once, (const void*)attn_fwd_kernel_v4, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
         attn_fwd_kernel_v4<<<grid, dim3(512), ATT_LDS, stream>>>(a);

@@ -45,12 +45,12 @@ def _check(ops, q, k, v, H, atol=8e-3):
     ref = _ref(q, k, v)
     got = _run(ops, q, k, v, H)
     torch.testing.assert_close(got.float().cpu(), ref, rtol=2 ** -7, atol=atol)
-    for ver in ("2", "3"):          # the previous kernels on the same data: equal to bf16 rounding of the output
+    for ver in ("2", "3", "4"):     # the previous kernels on the same data: equal to bf16 rounding of the output
         os.environ["HV_ATTN_VER"] = ver
         try:
             old = _run(ops, q, k, v, H)
         finally:
-            os.environ["HV_ATTN_VER"] = "4"
+            os.environ["HV_ATTN_VER"] = "5"
         torch.testing.assert_close(got.float().cpu(), old.float().cpu(), rtol=2 ** -6, atol=atol)
 
 
