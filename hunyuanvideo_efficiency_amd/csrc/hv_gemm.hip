@@ -116,8 +116,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // ---- epilogue shared by both main loops: lane holds, per (mi, n-repeat pair), 8 consecutive n of row m
-template <typename DT, int BN, int NREP>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[8][NREP], int m0, int n0, int wm, int wn, int fr, int fq) {
+template <typename DT, int MREP, int NREP>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mrow0, int ncol0, int fq) {
     auto unpack = [](const u32x4& w, float (&f)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -125,29 +125,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
             f[2 * i + 1] = DT::hi(w[i]);
         }
     };
-    const int mrow0 = m0 + wm * 128 + fr;
+    // mrow0: this lane's first output row (+ 16 per m-repeat); ncol0: the wave's first output column (+ 32 per n-repeat pair).
     // Every global read of the epilogue is issued in one batch per 32-column group BEFORE any of it is consumed (row indices
     // clamped instead of branched around, stores guarded): eight residual rows + eight row scales in flight together cost one
     // memory round trip; read one by one behind `if (m < M)` branches they cost sixteen per tile (~2 us each under load), which
     // was 30 us of the 64 us an fp8 K = 3072 tile took.
-    float rsc[8];
+    float rsc[MREP];
     if (g.a_scale) {
         const float wsc = bf2f(*g.w_scale);
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) rsc[mi] = g.a_scale[min(mrow0 + mi * 16, g.M - 1)] * wsc;
+        for (int mi = 0; mi < MREP; ++mi) rsc[mi] = g.a_scale[min(mrow0 + mi * 16, g.M - 1)] * wsc;
     } else {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) rsc[mi] = 1.0f;
+        for (int mi = 0; mi < MREP; ++mi) rsc[mi] = 1.0f;
     }
 #pragma unroll
     for (int np = 0; np < NREP / 2; ++np) {
-        const int n = n0 + wn * (BN / 4) + np * 32 + fq * 8;
+        const int n = ncol0 + np * 32 + fq * 8;
         if (n >= g.N) continue;
         float b[8], gt[8];
-        u32x4 rraw[8];
+        u32x4 rraw[MREP];
         if (g.res) {
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
+            for (int mi = 0; mi < MREP; ++mi)
                 rraw[mi] = *reinterpret_cast<const u32x4*>(g.res + (int64_t)min(mrow0 + mi * 16, g.M - 1) * g.ld_res + n);
         }
         if (g.bias) unpack(*reinterpret_cast<const u32x4*>(g.bias + n), b);
@@ -161,7 +161,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[8]
         const int64_t ldo = second ? g.ld1 : g.ld0;
         const int act = second ? g.act1 : g.act0;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
+        for (int mi = 0; mi < MREP; ++mi) {
             const int m = mrow0 + mi * 16;
             float v[8];
 #pragma unroll
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    gemm_epilogue<DT, BN, NREP>(g, acc, m0, n0, wm, wn, fr, fq);
+    gemm_epilogue<DT, 8, NREP>(g, acc, m0 + wm * 128 + fr, n0 + wn * (BN / 4), fq);
 }
 
 // =====================================================================================================================
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" : "+s"(ge.bias), "+s"(ge.gate), "+s"(ge.res), "+s"(ge.a_scale), "+s"(ge.w_scale), "+s"(ge.out0),
                  "+s"(ge.out1), "+s"(ge.out_f32) : : "memory");
     __builtin_amdgcn_sched_barrier(0);
-    gemm_epilogue<DT, 256, 4>(ge, acc, m0, n0, wm, wn, fr, fq);
+    gemm_epilogue<DT, 8, 4>(ge, acc, m0 + wm * 128 + fr, n0 + wn * 64, fq);
 }
 
 template <typename DT, bool CONV = false>
@@ -687,6 +687,203 @@ int launch_gemm8(GemmArgs& g, hipStream_t stream) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + 255) / 256;
     gemm8_kernel<DT, CONV><<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS8_BYTES, stream>>>(g);
+    return hv_check_launch();
+}
+
+// =====================================================================================================================
+// Pipelined 256 x 128 tile for the VAE's 128-channel convolutions (Cout <= 128: 39 % of the tiled decode ran on the 2-stage
+// 256 x 128 loop at ~0.8 PF).  Same ideas as gemm8_kernel - raw barriers, counted vmcnt, the two wave rows one barrier apart -
+// re-proportioned for the narrower tile:
+//   * 8 waves as 4 (M) x 2 (N), each 64 x 64 outputs = 4 x 4 accumulators (64 VGPRs; ~140 in all);
+//   * a K-tile is three 16-KiB units in consumption order: Am0 (rows wm*64 + [0,32) of all four wave rows), B (all 128 W rows),
+//     Am1; two phases per K-tile of 16 MFMAs each: (m0 x all n) after reading B (8) + A(m0) (4) fragments, (m1 x all n) after 4 more;
+//   * THREE K-tile buffers (144 KiB): every unit is issued two K-tiles ahead - phase 1 issues Am0 and B, phase 2 issues Am1 of
+//     tile t+2 into the buffer tile t-1 just left - so 4-5 units (64-80 KiB) are in flight behind vmcnt(10) / vmcnt(8);
+//   * K-tile count of a 3x3x3 conv is 27*cin/64, always a multiple of 3: the loop is unrolled by three tiles (static LDS offsets).
+// Arithmetic intensity is 85 flop per staged byte (256 x 256: 128), so the LDS-fill rate (L2 -> LDS, 66-73 GB/s per CU) caps this
+// tile near 1.5 PF.  conv mode only (plain N <= 128 GEMMs are tiny); gather offsets per tap from packed coordinates as in gemm8.
+constexpr int C128_UNIT = 16384, C128_BUF = 3 * C128_UNIT, C128_LDS = 3 * C128_BUF;   // 144 KiB
+
+__global__ __launch_bounds__(512, 2) void conv128_kernel(GemmArgs g) {
+    typedef F16T DT;
+    typedef DT::vec8 vec8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;          // waves 0-3 (wm 0,1) / 4-7 (wm 2,3) = the two waves of every SIMD
+
+    const int nwg = gridDim.x;
+    int lin;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = lin / g.tiles_n, tn = lin % g.tiles_n;       // tiles_n == 1 for every 128-channel layer: consecutive M tiles per XCD
+    const int m0 = tm * BM, n0 = tn * 128;
+
+    const int srow = tid >> 3, scp = tid & 7;
+    uint32_t a_o[2][2], w_o[2], tap_off[2][2] = {{0u, 0u}, {0u, 0u}};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = i * 64 + srow;                                    // LDS row of the unit
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int arow = (lr >> 5) * 64 + h * 32 + (lr & 31);           // tile row: wave row (lr>>5), its rows [h*32, h*32+32)
+            const int ar = min(m0 + arow, g.M - 1);
+            const int vw = (ar % g.cW) * g.mw, th = ar / g.cW;
+            a_o[h][i] = (uint32_t)((th / g.cH) * g.mt) | ((uint32_t)((th % g.cH) * g.mh) << 8) | ((uint32_t)vw << 20);
+        }
+        w_o[i] = (uint32_t)((int64_t)(min(n0 + lr, g.N - 1) - n0) * g.ldw * 2 + ((scp ^ swz_w(lr)) << 4));
+    }
+    const uint32_t a_chunk = (uint32_t)((scp ^ swz_a(srow)) << 4);
+    const int wave_lds = wave * 1024;
+    const char* a_base = reinterpret_cast<const char*>(g.A);
+    const char* w_tile = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * 2;
+    const int lg_cin = 31 - __builtin_clz((unsigned)g.cin);
+    auto conv_tap = [&](int h, int tap) {
+        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+        const uint32_t row_bytes = (uint32_t)g.lda * 2u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t c = a_o[h][i];
+            int ti = max((int)(c & 255u) + dt - 2, 0);
+            if (g.up_t) ti = ti == 0 ? 0 : 1 + ((ti - 1) >> 1);
+            const int hi = min(max((int)((c >> 8) & 4095u) + dh - 1, 0), g.bH - 1) >> g.up_hw;
+            const int wi = min(max((int)(c >> 20) + dw - 1, 0), g.bW - 1) >> g.up_hw;
+            tap_off[h][i] = (uint32_t)((ti * g.sH + hi) * g.sW + wi) * row_bytes + a_chunk;
+        }
+    };
+    // unit U (0 Am0, 1 B, 2 Am1) of K-tile `tile` into buffer `buf`
+    auto stage = [&](auto Uc, int buf, int tile) {
+        constexpr int U = decltype(Uc)::value;
+        char* dst = smem + buf * C128_BUF + U * C128_UNIT + wave_lds;
+        uint64_t bv;
+        if constexpr (U != 1) {
+            constexpr int h = U >> 1;
+            const int tap = (tile * BK) >> lg_cin, c0 = tile * BK - (tap << lg_cin);
+            if (c0 == 0) conv_tap(h, tap);
+            bv = reinterpret_cast<uint64_t>(a_base + c0 * 2);
+        } else {
+            bv = reinterpret_cast<uint64_t>(w_tile + (int64_t)tile * (BK * 2));
+        }
+        asm volatile("" : "+s"(bv));
+        const char* b = reinterpret_cast<const char*>(bv);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint32_t o = U == 1 ? w_o[i] : tap_off[U >> 1][i];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b + o), (lds_ptr_t)(dst + i * 8192), 16, 0, 0);
+        }
+    };
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int a_rd = (wm * 32 + fr) * 128 + ((fq ^ swz_a(fr)) << 4);                         // + mi' * 2048 (mi' = 0, 1)
+    const int w_lr = wn * 64 + (fr >> 2) * 8 + (fr & 3);                                     // + (ni>>1)*32 rows + (ni&1)*4 rows
+    const int w_rd = w_lr * 128 + ((fq ^ swz_w(w_lr)) << 4);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    vec8 af[2][2], wf[4][2];
+
+    auto readA = [&](auto BUFc, auto MHc) {
+        constexpr int BUF = decltype(BUFc)::value, MH = decltype(MHc)::value;
+        const char* base = smem + BUF * C128_BUF + (MH ? 2 : 0) * C128_UNIT;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi][ks] = *reinterpret_cast<const vec8*>(base + ((a_rd ^ (ks << 6)) + mi * 2048));
+    };
+    auto readB = [&](auto BUFc) {
+        constexpr int BUF = decltype(BUFc)::value;
+        const char* base = smem + BUF * C128_BUF + C128_UNIT;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wf[ni][ks] = *reinterpret_cast<const vec8*>(base + ((w_rd ^ (ks << 6)) + (ni >> 1) * 4096 + (ni & 1) * 512));
+    };
+    auto mma = [&](auto MHc) {
+        constexpr int MH = decltype(MHc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[MH * 2 + mi][ni] = DT::mfma(wf[ni][ks], af[mi][ks], acc[MH * 2 + mi][ni]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+#define HV_C_SYNC(VM)                                                 \
+    asm volatile("s_waitcnt vmcnt(" #VM ")\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_barrier();                                     \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_setprio(1);
+#define HV_C_END()                                                    \
+    __builtin_amdgcn_s_setprio(0);                                    \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_barrier();                                     \
+    __builtin_amdgcn_sched_barrier(0);
+    // KIND 0 steady (issues for tile t+2; vmcnt 10 / 8), 1 = tile nkt-2 (no issue; 6 / 2), 2 = tile nkt-1 (0 / 0)
+    auto tile_fn = [&](auto BUFc, auto KINDc, int t) {
+        constexpr int BUF = decltype(BUFc)::value, KIND = decltype(KINDc)::value;
+        constexpr int NB = (BUF + 2) % 3;                 // buffer of tile t+2 = the one tile t-1 just left
+        using B = std::integral_constant<int, BUF>;
+        readB(B{});
+        __builtin_amdgcn_sched_barrier(0);
+        readA(B{}, I0{});
+        if constexpr (KIND == 0) { stage(I0{}, NB, t + 2); stage(I1{}, NB, t + 2); }
+        if constexpr (KIND == 0) { HV_C_SYNC(10) } else if constexpr (KIND == 1) { HV_C_SYNC(6) } else { HV_C_SYNC(0) }
+        mma(I0{});
+        HV_C_END()
+        readA(B{}, I1{});
+        if constexpr (KIND == 0) stage(I2{}, NB, t + 2);
+        if constexpr (KIND == 0) { HV_C_SYNC(8) } else if constexpr (KIND == 1) { HV_C_SYNC(2) } else { HV_C_SYNC(0) }
+        mma(I1{});
+        HV_C_END()
+    };
+
+    const int nkt = g.K / BK;      // a multiple of 3, >= 27 (host-side dispatch)
+    stage(I0{}, 0, 0); stage(I1{}, 0, 0); stage(I2{}, 0, 0);
+    stage(I0{}, 1, 1); stage(I1{}, 1, 1); stage(I2{}, 1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wm >= 2) __builtin_amdgcn_s_barrier();      // the second wave row group runs one barrier interval behind the first
+    __builtin_amdgcn_sched_barrier(0);
+    int t = 0;
+    for (; t + 3 < nkt; t += 3) {                  // tiles 0 .. nkt-4 (steady: t + 2 <= nkt - 1 for each)
+        tile_fn(I0{}, I0{}, t);
+        tile_fn(I1{}, I0{}, t + 1);
+        tile_fn(I2{}, I0{}, t + 2);
+    }
+    tile_fn(I0{}, I0{}, t);                        // tile nkt-3, still steady
+    tile_fn(I1{}, I1{}, t + 1);
+    tile_fn(I2{}, I2{}, t + 2);
+    if (wm < 2) __builtin_amdgcn_s_barrier();
+#undef HV_C_SYNC
+#undef HV_C_END
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) asm volatile("" : : "v"(acc[mi][ni]));
+    GemmArgs ge = g;
+    asm volatile("s_waitcnt vmcnt(0)" : "+s"(ge.bias), "+s"(ge.gate), "+s"(ge.res), "+s"(ge.a_scale), "+s"(ge.w_scale), "+s"(ge.out0),
+                 "+s"(ge.out1), "+s"(ge.out_f32) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_epilogue<DT, 4, 4>(ge, acc, m0 + wm * 64 + fr, n0 + wn * 64, fq);
+}
+
+int launch_conv128(GemmArgs& g, hipStream_t stream) {
+    static HvPerDeviceOnce once;
+    if (hv_set_max_lds(once, (const void*)conv128_kernel, C128_LDS) != HV_OK) return HV_ERR_LAUNCH;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + 127) / 128;
+    conv128_kernel<<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), C128_LDS, stream>>>(g);
     return hv_check_launch();
 }
 
@@ -704,7 +901,17 @@ template <typename DT, bool CONV>
 int launch(GemmArgs& g, hipStream_t stream) {
     // narrow outputs (N <= 128: the VAE's 128-channel and output convs, small projections) take the 256x128 tile so that at
     // most half a tile of MFMA work is padding
-    if (g.N <= 128) return launch_bn<DT, CONV, 128>(g, stream);
+    if (g.N <= 128) {
+        if constexpr (CONV && std::is_same<DT, F16T>::value) {
+            // the pipelined 256 x 128 conv tile: cin a power of two >= 128 (a tap spans >= 2 K-tiles), 27*cin/64 K-tiles (a multiple of 3),
+            // coordinates within the packing
+            const bool pow2 = (g.cin & (g.cin - 1)) == 0;
+            if (pow2 && g.cin >= 128 && (g.K / BK) % 3 == 0 && g.K / BK >= 6 && g.cT * g.mt < 256 && g.bH <= 4096 && g.bW <= 4096 &&
+                !hv_gemm_force_2stage())
+                return launch_conv128(g, stream);
+        }
+        return launch_bn<DT, CONV, 128>(g, stream);
+    }
     if constexpr (!CONV) {
         if (g.K >= 3 * BK && !hv_gemm_force_2stage()) return launch_gemm8<DT>(g, stream);     // pipelined main loop
     } else if constexpr (std::is_same<DT, F16T>::value) {
