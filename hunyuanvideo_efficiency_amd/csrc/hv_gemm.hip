@@ -116,7 +116,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // ---- epilogue shared by both main loops: lane holds, per (mi, n-repeat pair), 8 consecutive n of row m
-template <typename DT, int MREP, int NREP>
+template <typename DT, int MREP, int NREP, int MSTEP = 16>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mrow0, int ncol0, int fq) {
     auto unpack = [](const u32x4& w, float (&f)[8]) {
 #pragma unroll
@@ -125,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
             f[2 * i + 1] = DT::hi(w[i]);
         }
     };
-    // mrow0: this lane's first output row (+ 16 per m-repeat); ncol0: the wave's first output column (+ 32 per n-repeat pair).
+    // mrow0: this lane's first output row (+ MSTEP per m-repeat); ncol0: the wave's first output column (+ 32 per n-repeat pair).
     // Every global read of the epilogue is issued in one batch per 32-column group BEFORE any of it is consumed (row indices
     // clamped instead of branched around, stores guarded): eight residual rows + eight row scales in flight together cost one
     // memory round trip; read one by one behind `if (m < M)` branches they cost sixteen per tile (~2 us each under load), which
@@ -134,7 +134,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
     if (g.a_scale) {
         const float wsc = bf2f(*g.w_scale);
 #pragma unroll
-        for (int mi = 0; mi < MREP; ++mi) rsc[mi] = g.a_scale[min(mrow0 + mi * 16, g.M - 1)] * wsc;
+        for (int mi = 0; mi < MREP; ++mi) rsc[mi] = g.a_scale[min(mrow0 + mi * MSTEP, g.M - 1)] * wsc;
     } else {
 #pragma unroll
         for (int mi = 0; mi < MREP; ++mi) rsc[mi] = 1.0f;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
         if (g.res) {
 #pragma unroll
             for (int mi = 0; mi < MREP; ++mi)
-                rraw[mi] = *reinterpret_cast<const u32x4*>(g.res + (int64_t)min(mrow0 + mi * 16, g.M - 1) * g.ld_res + n);
+                rraw[mi] = *reinterpret_cast<const u32x4*>(g.res + (int64_t)min(mrow0 + mi * MSTEP, g.M - 1) * g.ld_res + n);
         }
         if (g.bias) unpack(*reinterpret_cast<const u32x4*>(g.bias + n), b);
         else {
@@ -162,7 +162,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
         const int act = second ? g.act1 : g.act0;
 #pragma unroll
         for (int mi = 0; mi < MREP; ++mi) {
-            const int m = mrow0 + mi * 16;
+            const int m = mrow0 + mi * MSTEP;
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -887,6 +887,264 @@ int launch_conv128(GemmArgs& g, hipStream_t stream) {
     return hv_check_launch();
 }
 
+// =====================================================================================================================
+// 256 x 128 conv tile with W-SHIFT REUSE of the staged activations (cW divides 256, unit stride along W).
+//
+// conv128_kernel re-gathers the 256 activation rows for each of the 27 taps although the three taps (dt, dh, 0..2) read the
+// same source rows displaced by one output position: staged per K-tile it moves 48 KiB for 4.2 MFLOP and is bound by the
+// L2 -> LDS fill (52 GB/s per CU measured, 1.0-1.16 PF).  Here the K loop runs in GROUPS of three K-tiles - one (dt, dh) row of
+// taps and one 64-channel chunk - that share ONE staged activation block: S[j] = the source row of output j for the centre tap
+// dw = 1, and the fragment reads of tap dw take row j + dw - 1 of the same block.  A tile starts on a multiple of cW and cW
+// divides 256, so j - 1 / j + 1 only leave the block where the conv clamps anyway (w = 0 / w = cW - 1): those lanes read row j
+// itself (replicate padding), decided once per lane when the fragment addresses are formed.  Per group 32 KiB of activations +
+// 3 x 16 KiB of weights are staged instead of 144 KiB: 153 flop per staged byte (was 85).
+// The LDS array (fragment reads 256 B/clk + the DMA's writes) is as busy as the matrix pipe with 64 x 64 outputs per wave, and a
+// 16-row fragment read displaced by one LDS row is a 2-way bank conflict under any XOR swizzle (no pairing of the 16 rows
+// survives all three displacements), so the rows are also PERMUTED: tile row j sits at LDS row (j & 3) * 64 + (j >> 2), a
+// lane's four m-repeats are the four consecutive tile rows 4*fr .. 4*fr + 3 (block b = LDS rows b*64 ..), and "row j + 1" of
+// block b IS block b + 1 in the same lane's registers.  The three taps of a group then need six fragment blocks - blocks 0..3,
+// "row j - 1 of block 0" (block 3 one LDS row up) and "row j + 1 of block 3" (block 0 one row down) - instead of twelve, only
+// the last two displaced: 12 A-fragment reads per group instead of 24 (+ 24 of W).
+// The sum over K is taken in the order (dt, dh, channel chunk, dw) instead of (tap, channel chunk): a fixed order, so results
+// are run-to-run identical, but not bit-identical to conv128_kernel's (fp32 accumulation, fp16 output).
+//
+// LDS (128 KiB): weights in a ring of four 16-KiB K-tile slots, each issued THREE K-tiles ahead; activations double-buffered
+// per group (2 x 32 KiB, rows linear), the halves of group g+1 issued in phases 1 and 5 of group g.  Two phases per K-tile,
+// split by N (phase 1: the wave's 64 x 32 left half after 8 A + 4 W fragment reads, phase 2: the right half after 4 more W reads),
+// so the A fragments of a tap are read once.  Counted waits (two loads per thread and 16-KiB unit):
+//     issue   P1a W(t+3) | P2a A1(g+1) | P1b W(t+3) | P2b -        | P1c W(t+3) | P2c A0(g+2)
+//     vmcnt       -      |     8       |     -      |  8           |     -      |  6          (before the barrier ending the phase)
+// 4-5 units (64-80 KiB per CU) stay in flight across the raw barriers; the two wave groups (waves 0-3 / 4-7) run one barrier
+// apart as in gemm8_kernel.  WAR: W(t+3) goes to the slot of W(t-1), last read in phase 2 of tile t-1; A0(g+2) / A1(g+1) go to
+// the buffer of group g / g-1 whose last fragment read is in phase 1 of the group's third tile - each at least one barrier
+// (for the other wave group: its lgkmcnt(0) + one barrier) before the issue.
+constexpr int CS_SLOT = 16384, CS_A0 = 4 * CS_SLOT, CS_ABUF = 32768, CS_LDS = CS_A0 + 2 * CS_ABUF;   // 128 KiB
+
+__global__ __launch_bounds__(512, 2) void conv128s_kernel(GemmArgs g) {
+    typedef F16T DT;
+    typedef DT::vec8 vec8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = gridDim.x;
+    int lin;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = lin * BM;          // tiles_n == 1
+
+    const int srow = tid >> 3, scp = tid & 7;
+    uint32_t a_o[2][2], w_o[2], tap_off[2][2] = {{0u, 0u}, {0u, 0u}};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int R = u * 128 + i * 64 + srow;                          // LDS row R holds tile row 4 * (R & 63) + (R >> 6)
+            const int ar = min(m0 + (((R & 63) << 2) | (R >> 6)), g.M - 1);
+            const int vw = ar % g.cW, th = ar / g.cW;
+            a_o[u][i] = (uint32_t)((th / g.cH) * g.mt) | ((uint32_t)((th % g.cH) * g.mh) << 8) | ((uint32_t)vw << 20);
+        }
+        const int lr = i * 64 + srow;
+        w_o[i] = (uint32_t)((int64_t)min(lr, g.N - 1) * g.ldw * 2 + ((scp ^ swz_w(lr)) << 4));
+    }
+    const uint32_t a_chunk = (uint32_t)((scp ^ swz_a(srow)) << 4);
+    const int wave_lds = wave * 1024;
+    const char* a_base = reinterpret_cast<const char*>(g.A);
+    const char* w_base = reinterpret_cast<const char*>(g.W);
+    const int lg_cpk = 31 - __builtin_clz((unsigned)g.cin) - 6;      // log2(K-tiles per tap)
+    const int cpk_mask = (1 << lg_cpk) - 1;
+    auto conv_row = [&](int u, int dt, int dh) {                     // gather offsets of the centre tap (dt, dh, 1)
+        const uint32_t row_bytes = (uint32_t)g.lda * 2u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t c = a_o[u][i];
+            int ti = max((int)(c & 255u) + dt - 2, 0);
+            if (g.up_t) ti = ti == 0 ? 0 : 1 + ((ti - 1) >> 1);
+            const int hi = min(max((int)((c >> 8) & 4095u) + dh - 1, 0), g.bH - 1) >> g.up_hw;
+            const int wi = (int)(c >> 20) >> g.up_hw;
+            tap_off[u][i] = (uint32_t)((ti * g.sH + hi) * g.sW + wi) * row_bytes + a_chunk;
+        }
+    };
+    auto stageA = [&](auto Uc, int grp) {                            // half U of group grp's activation block
+        constexpr int U = decltype(Uc)::value;
+        char* dst = smem + CS_A0 + (grp & 1) * CS_ABUF + U * 16384 + wave_lds;
+        const int dtdh = grp >> lg_cpk, cc = grp & cpk_mask;
+        if (cc == 0) conv_row(U, dtdh / 3, dtdh % 3);
+        uint64_t bv = reinterpret_cast<uint64_t>(a_base + cc * (BK * 2));
+        asm volatile("" : "+s"(bv));
+        const char* b = reinterpret_cast<const char*>(bv);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint32_t o = tap_off[U][i];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b + o), (lds_ptr_t)(dst + i * 8192), 16, 0, 0);
+        }
+    };
+    auto stageB = [&](int tile) {                                    // weights of K-tile `tile` (loop order) into slot tile & 3
+        char* dst = smem + (tile & 3) * CS_SLOT + wave_lds;
+        const int grp = tile / 3, dw = tile - grp * 3;
+        const int kt = ((((grp >> lg_cpk) * 3 + dw) << lg_cpk) + (grp & cpk_mask));      // K-tile index in the weight layout
+        uint64_t bv = reinterpret_cast<uint64_t>(w_base + (int64_t)kt * (BK * 2));
+        asm volatile("" : "+s"(bv));
+        const char* b = reinterpret_cast<const char*>(bv);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint32_t o = w_o[i];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b + o), (lds_ptr_t)(dst + i * 8192), 16, 0, 0);
+        }
+    };
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment addresses: this lane's tile rows are j = wm*64 + 4*fr + b, b = 0..3, at LDS rows b*64 + wm*16 + fr; row j - 1 of
+    // b = 0 is block 3 one LDS row up, row j + 1 of b = 3 is block 0 one LDS row down - unless the conv clamps there (w = 0 /
+    // w = cW - 1, which only b = 0 / b = 3 can be since 4 | cW): then the lane reads its own row j again
+    int a_rd[6];
+    {
+        const int rb = wm * 16 + fr, jw = (m0 + wm * 64 + 4 * fr) % g.cW;
+        auto addr = [&](int R) { return CS_A0 + R * 128 + ((fq ^ swz_a(R)) << 4); };
+#pragma unroll
+        for (int b = 0; b < 4; ++b) a_rd[b] = addr(b * 64 + rb);
+        a_rd[4] = addr(jw == 0 ? rb : 192 + rb - 1);
+        a_rd[5] = addr(jw + 3 == g.cW - 1 ? 192 + rb : rb + 1);
+    }
+    const int w_lr = wn * 64 + (fr >> 2) * 8 + (fr & 3);                                     // + (ni>>1)*32 rows + (ni&1)*4 rows
+    const int w_rd = w_lr * 128 + ((fq ^ swz_w(w_lr)) << 4);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    vec8 ab[4][2], ax[2], wf[2][2];       // blocks 0..3 (kept for the three taps of a group), the extra block of tap 0 / tap 2
+
+    auto readA = [&](vec8 (&dst)[2], int a) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) dst[ks] = *reinterpret_cast<const vec8*>(smem + (a ^ (ks << 6)));
+    };
+    auto readB = [&](auto NHc, int wslot) {
+        constexpr int NH = decltype(NHc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const char* base = smem + ((w_rd ^ (ks << 6)) + wslot) + NH * 4096;
+#pragma unroll
+            for (int nl = 0; nl < 2; ++nl) wf[nl][ks] = *reinterpret_cast<const vec8*>(base + nl * 512);
+        }
+    };
+    auto mma = [&](auto DWc, auto NHc) {
+        constexpr int DW = decltype(DWc)::value, NH = decltype(NHc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int b = mi + DW - 1;                 // block holding row j + DW - 1 of output row j = ... + mi
+                const vec8& a = b < 0 || b > 3 ? ax[ks] : ab[b < 0 ? 0 : b > 3 ? 3 : b][ks];
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl) acc[mi][NH * 2 + nl] = DT::mfma(wf[nl][ks], a, acc[mi][NH * 2 + nl]);
+            }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+#define HV_S_SYNC_NOVM()                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_barrier();                                     \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_setprio(1);
+#define HV_S_SYNC(VM)                                                 \
+    asm volatile("s_waitcnt vmcnt(" #VM ")\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_barrier();                                     \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_setprio(1);
+#define HV_S_END()                                                    \
+    __builtin_amdgcn_s_setprio(0);                                    \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    __builtin_amdgcn_s_barrier();                                     \
+    __builtin_amdgcn_sched_barrier(0);
+    // KIND 0: steady group; 1: the last but one (no A0 of group g+2); 2: the last (nothing left to issue)
+    auto tile_fn = [&](auto DWc, auto KINDc, int grp) {
+        constexpr int DW = decltype(DWc)::value, KIND = decltype(KINDc)::value;
+        const int t = grp * 3 + DW;
+        const int wslot = (t & 3) * CS_SLOT, abuf = (grp & 1) * CS_ABUF;
+        // A fragment reads of a group: tap 0 phase 1: row j-1 of block 0 + blocks 0..2 (8 reads), phase 2: block 3; tap 2 phase 1:
+        // row j+1 of block 3 (into the registers tap 0's extra block left) - 12 ds_read_b128 per group instead of 24
+        if constexpr (DW == 0) {
+            readA(ax, a_rd[4] + abuf);
+            readA(ab[0], a_rd[0] + abuf);
+            readA(ab[1], a_rd[1] + abuf);
+            readA(ab[2], a_rd[2] + abuf);
+        }
+        if constexpr (DW == 2) readA(ax, a_rd[5] + abuf);
+        readB(I0{}, wslot);
+        if constexpr (KIND < 2) stageB(t + 3);
+        HV_S_SYNC_NOVM()
+        mma(DWc, I0{});
+        HV_S_END()
+        if constexpr (DW == 0) readA(ab[3], a_rd[3] + abuf);
+        readB(I1{}, wslot);
+        if constexpr (KIND < 2 && DW == 0) stageA(I1{}, grp + 1);
+        if constexpr (KIND == 0 && DW == 2) stageA(I0{}, grp + 2);
+        if constexpr (KIND == 0) {
+            if constexpr (DW == 2) { HV_S_SYNC(6) } else { HV_S_SYNC(8) }
+        } else if constexpr (KIND == 1) {
+            if constexpr (DW == 2) { HV_S_SYNC(4) } else { HV_S_SYNC(8) }
+        } else {
+            if constexpr (DW == 0) { HV_S_SYNC(2) } else { HV_S_SYNC(0) }
+        }
+        mma(DWc, I1{});
+        HV_S_END()
+    };
+
+    const int ngrp = g.K / (3 * BK);      // >= 2 (host-side dispatch)
+    stageA(I0{}, 0); stageB(0); stageA(I1{}, 0); stageB(1); stageB(2); stageA(I0{}, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wm >= 2) __builtin_amdgcn_s_barrier();      // the second wave group runs one barrier interval behind the first
+    __builtin_amdgcn_sched_barrier(0);
+    int grp = 0;
+    for (; grp < ngrp - 2; ++grp) {
+        tile_fn(I0{}, I0{}, grp);
+        tile_fn(I1{}, I0{}, grp);
+        tile_fn(I2{}, I0{}, grp);
+    }
+    tile_fn(I0{}, I1{}, grp);
+    tile_fn(I1{}, I1{}, grp);
+    tile_fn(I2{}, I1{}, grp);
+    ++grp;
+    tile_fn(I0{}, I2{}, grp);
+    tile_fn(I1{}, I2{}, grp);
+    tile_fn(I2{}, I2{}, grp);
+    if (wm < 2) __builtin_amdgcn_s_barrier();
+#undef HV_S_SYNC
+#undef HV_S_SYNC_NOVM
+#undef HV_S_END
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) asm volatile("" : : "v"(acc[mi][ni]));
+    GemmArgs ge = g;
+    asm volatile("s_waitcnt vmcnt(0)" : "+s"(ge.bias), "+s"(ge.gate), "+s"(ge.res), "+s"(ge.a_scale), "+s"(ge.w_scale), "+s"(ge.out0),
+                 "+s"(ge.out1), "+s"(ge.out_f32) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_epilogue<DT, 4, 4, 1>(ge, acc, m0 + wm * 64 + 4 * fr, wn * 64, fq);
+}
+
+int launch_conv128s(GemmArgs& g, hipStream_t stream) {
+    static HvPerDeviceOnce once;
+    if (hv_set_max_lds(once, (const void*)conv128s_kernel, CS_LDS) != HV_OK) return HV_ERR_LAUNCH;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = 1;
+    conv128s_kernel<<<dim3((unsigned)g.tiles_m), dim3(512), CS_LDS, stream>>>(g);
+    return hv_check_launch();
+}
+
 template <typename DT, bool CONV, int BN>
 int launch_bn(GemmArgs& g, hipStream_t stream) {
     static HvPerDeviceOnce once;     // one per template instantiation
@@ -907,8 +1165,12 @@ int launch(GemmArgs& g, hipStream_t stream) {
             // coordinates within the packing
             const bool pow2 = (g.cin & (g.cin - 1)) == 0;
             if (pow2 && g.cin >= 128 && (g.K / BK) % 3 == 0 && g.K / BK >= 6 && g.cT * g.mt < 256 && g.bH <= 4096 && g.bW <= 4096 &&
-                !hv_gemm_force_2stage())
+                !hv_gemm_force_2stage()) {
+                // unit stride along W, clamp extent = output width, output rows of a tile = whole W rows: the W-shift-reuse kernel
+                static const bool no_shift = getenv("HV_CONV_NOSHIFT") != nullptr;
+                if (g.mw == 1 && g.bW == g.cW && g.cW <= 256 && 256 % g.cW == 0 && g.cW % 4 == 0 && !no_shift) return launch_conv128s(g, stream);
                 return launch_conv128(g, stream);
+            }
         }
         return launch_bn<DT, CONV, 128>(g, stream);
     }

@@ -64,6 +64,40 @@ def test_conv3d_causal(V, T, H, W, Cin, Cout):
     torch.testing.assert_close(uncl(got, T, H, W), E.r(res + ref), rtol=2e-3, atol=4e-3)
 
 
+# The 128-channel layers (Cout <= 128, Cin a power of two >= 128) whose output width divides 256 take the W-shift-reuse kernel
+# (one staged activation block per (dt, dh, channel chunk) serves the three dw taps): widths 8 .. 256, several 256-row tiles, a
+# ragged last tile, the clamp lanes at w = 0 / W - 1 in the middle of a tile (W < 256), both Cin, a narrow Cout (conv_out), the
+# residual epilogue and the fused nearest upsample.  W = 12 (does not divide 256) keeps the per-tap kernel covered.
+@pytest.mark.parametrize("T,H,W,Cin,Cout", [(2, 5, 8, 128, 128), (3, 3, 64, 128, 128), (1, 5, 128, 256, 128), (2, 3, 256, 128, 8),
+                                            (1, 2, 256, 256, 128), (2, 7, 12, 128, 128), (4, 9, 32, 128, 72)])
+def test_conv3d_causal_128_channel_layers(V, T, H, W, Cin, Cout):
+    x = E.r(U((1, Cin, T, H, W), "cs.x"))
+    w = E.r(U((Cout, Cin, 3, 3, 3), "cs.w", 1 / math.sqrt(27 * Cin)))
+    b = E.r(U((Cout,), "cs.b", 0.1))
+    ref = R.causal_conv3d(x, w, b, E)
+    got = V.conv3d_causal(cl(x), taps(w), b.to(DEV).to(F16), T, H, W, Cin, Cout)
+    torch.testing.assert_close(uncl(got, T, H, W), ref, rtol=2e-3, atol=2e-3)
+    again = V.conv3d_causal(cl(x), taps(w), b.to(DEV).to(F16), T, H, W, Cin, Cout)
+    assert torch.equal(got, again)                      # fixed summation order: run-to-run identical
+    res = E.r(U((1, Cout, T, H, W), "cs.res"))
+    got = V.conv3d_causal(cl(x), taps(w), b.to(DEV).to(F16), T, H, W, Cin, Cout, res=cl(res))
+    torch.testing.assert_close(uncl(got, T, H, W), E.r(res + ref), rtol=2e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("factor,thw", [((2, 2, 2), (2, 3, 16)), ((1, 2, 2), (2, 2, 64))])
+def test_conv3d_128_channel_fused_upsample(V, factor, thw):
+    T, H, W = thw
+    C = 128
+    x = E.r(U((1, C, T, H, W), "us.x"))
+    w = E.r(U((C, C, 3, 3, 3), "us.w", 1 / math.sqrt(27 * C)))
+    b = E.r(U((C,), "us.b", 0.1))
+    up = R.upsample_causal(x, factor)
+    ref = R.causal_conv3d(up, w, b, E)
+    T2, H2, W2 = up.shape[2:]
+    got = V.conv3d_causal(cl(x), taps(w), b.to(DEV).to(F16), T2, H2, W2, C, C, up_t=factor[0] == 2, up_hw=True)
+    torch.testing.assert_close(uncl(got, T2, H2, W2), ref, rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("factor", [(2, 2, 2), (1, 2, 2)])
 def test_conv3d_with_fused_upsample(V, factor):
     T, H, W, C = 3, 5, 4, 64
