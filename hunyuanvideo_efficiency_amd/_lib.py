@@ -51,6 +51,7 @@ SIGNATURES = {
     "hv_groupnorm_apply_f16": [_p, _l, _p, _l, _l, _i, _p, _i, _p],
     "hv_softmax_rows_f32_f16": [_p, _l, _p, _l, _i, _i, _i, _f, _p],
     "hv_transpose_16b": [_p, _l, _p, _l, _i, _i, _p],
+    "hv_conv3d_upsampled_subpixel_f16": [_p, _l, _p, _p, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p],
     "hv_conv3d_causal_strided_f16": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hv_temporal_resample_f16": [_p, _l, _p, _l, _i, _l, _i, _i, _i, _i, _p],
     "hv_vae_latent_tile_f16": [_p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _p, _p],

@@ -101,6 +101,24 @@ struct GemmArgs {
     // conv mode (ksz = 3): output grid cT x cH x cW, source tensor sT x sH x sW (differs when upsampling), cin per tap
     int cT, cH, cW, sT, sH, sW, up_t, up_hw, cin;
     int mt, mh, mw, bH, bW;   // strided conv: source coordinate = output coordinate * m; bH/bW: extent the index is clamped to
+    // sub-pixel form of (nearest upsample -> conv), see gemm8_kernel<.., SP>: M tiles [sp_tile0[c], sp_tile0[c+1]) belong to output
+    // parity class c (sp_rows[c] class-local rows = source-grid voxels), weights [class][N][sp_ntap * cin], tap offsets from sp_tab
+    int sp_tile0[9], sp_rows[8], sp_ntap;
+    const uint32_t* sp_tab;   // [class][sp_ntap]: (ot + 8) | (oh + 8) << 4 | (ow + 8) << 8, source voxel = clamp(class voxel + offset)
+};
+
+// output row of class-local voxel m of parity class (pt, ph, pw): the class's voxels are the source grid (frames x sH x sW), output
+// (t, h, w) = (2 kt + pt | kt, 2 kh + ph, 2 kw + pw) in the cT x cH x cW output grid
+struct SpRowMap {
+    int sH, sW, cH, cW, up_t, pt, ph, pw;
+    __device__ __forceinline__ int64_t operator()(int m) const {
+        const int kw = m % sW, th = m / sW, kh = th % sH, kt = th / sH;
+        const int t = up_t ? 2 * kt + pt : kt;
+        return ((int64_t)t * cH + 2 * kh + ph) * cW + 2 * kw + pw;
+    }
+};
+struct IdRowMap {
+    __device__ __forceinline__ int64_t operator()(int m) const { return m; }
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -116,8 +134,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // ---- epilogue shared by both main loops: lane holds, per (mi, n-repeat pair), 8 consecutive n of row m
-template <typename DT, int MREP, int NREP, int MSTEP = 16>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mrow0, int ncol0, int fq) {
+template <typename DT, int MREP, int NREP, int MSTEP = 16, typename RowMap = IdRowMap>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mrow0, int ncol0, int fq,
+                                              const RowMap& rowmap = RowMap()) {
     auto unpack = [](const u32x4& w, float (&f)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -130,6 +149,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
     // clamped instead of branched around, stores guarded): eight residual rows + eight row scales in flight together cost one
     // memory round trip; read one by one behind `if (m < M)` branches they cost sixteen per tile (~2 us each under load), which
     // was 30 us of the 64 us an fp8 K = 3072 tile took.
+    int64_t orow[MREP];                     // output (and residual) row of each m-repeat; clamped rows are loaded, never stored
+#pragma unroll
+    for (int mi = 0; mi < MREP; ++mi) orow[mi] = rowmap(min(mrow0 + mi * MSTEP, g.M - 1));
     float rsc[MREP];
     if (g.a_scale) {
         const float wsc = bf2f(*g.w_scale);
@@ -148,7 +170,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
         if (g.res) {
 #pragma unroll
             for (int mi = 0; mi < MREP; ++mi)
-                rraw[mi] = *reinterpret_cast<const u32x4*>(g.res + (int64_t)min(mrow0 + mi * MSTEP, g.M - 1) * g.ld_res + n);
+                rraw[mi] = *reinterpret_cast<const u32x4*>(g.res + orow[mi] * g.ld_res + n);
         }
         if (g.bias) unpack(*reinterpret_cast<const u32x4*>(g.bias + n), b);
         else {
@@ -171,7 +193,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
             }
             if (g.out_f32) {
                 if (m < g.M) {
-                    float4* o = reinterpret_cast<float4*>(g.out_f32 + (int64_t)m * g.ld0 + n);
+                    float4* o = reinterpret_cast<float4*>(g.out_f32 + orow[mi] * g.ld0 + n);
                     o[0] = make_float4(v[0], v[1], v[2], v[3]);
                     o[1] = make_float4(v[4], v[5], v[6], v[7]);
                 }
@@ -198,7 +220,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
             u32x4 w;
 #pragma unroll
             for (int i = 0; i < 4; ++i) w[i] = DT::pack(v[2 * i], v[2 * i + 1]);
-            if (m < g.M) *reinterpret_cast<u32x4*>(obase + (int64_t)m * ldo) = w;
+            if (m < g.M) *reinterpret_cast<u32x4*>(obase + orow[mi] * ldo) = w;
         }
     }
 }
@@ -397,7 +419,7 @@ constexpr int HT_BYTES = 16384;            // half-tile: 128 rows x 64 k x 2 B
 constexpr int BUF8_BYTES = 4 * HT_BYTES;   // [Am0 | Bn0 | Bn1 | Am1] of one K-tile
 constexpr int LDS8_BYTES = 2 * BUF8_BYTES; // 128 KiB
 
-template <typename DT, bool CONV = false>
+template <typename DT, bool CONV = false, bool SP = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     typedef typename DT::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -416,7 +438,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const int band_m0 = band * GROUP_M;
     const int gm = min(GROUP_M, g.tiles_m - band_m0);
     const int tm = band_m0 + rem % gm, tn = rem / gm;
-    const int m0 = tm * BM, n0 = tn * 256;
+    int m0 = tm * BM;
+    const int n0 = tn * 256;
+    // sub-pixel mode: the M tile's output parity class and its class-local rows
+    int sp_c = 0, sp_M = g.M;
+    if constexpr (SP) {
+#pragma unroll
+        for (int c = 1; c < 8; ++c) sp_c += tm >= g.sp_tile0[c] ? 1 : 0;
+        m0 = (tm - g.sp_tile0[sp_c]) * BM;
+        sp_M = g.sp_rows[sp_c];
+    }
+    const int sp_pt = g.up_t ? sp_c >> 2 : 0;
 
     // ---- staging: thread -> (row srow of a 64-row piece, 16-B chunk position scp); 2 pieces per half-tile
     const int srow = tid >> 3, scp = tid & 7;
@@ -430,9 +462,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
                 // conv mode: row = output voxel.  Its (t, h, w) source coordinates (already multiplied by the stride) are kept PACKED
                 // in one register; the byte offset of the current tap's source row is re-formed from them only when the half-tile
                 // stream this row belongs to crosses into a new tap (every cin/64 K-tiles), see conv_tap().
+                if constexpr (SP) {
+                    // sub-pixel mode: row = voxel (kt, kh, kw) of the SOURCE grid; the frame coordinate is the k of "taps on frames
+                    // k-1, k" (odd frames of a temporally upsampled output: k = kt + 1)
+                    const int ar = min(m0 + arow, sp_M - 1);
+                    const int kw = ar % g.sW, th = ar / g.sW;
+                    a_o[h][i] = (uint32_t)(th / g.sH + sp_pt) | ((uint32_t)(th % g.sH) << 8) | ((uint32_t)kw << 20);
+                } else {
                 const int ar = min(m0 + arow, g.M - 1);
                 const int vw = (ar % g.cW) * g.mw, th = ar / g.cW;
                 a_o[h][i] = (uint32_t)((th / g.cH) * g.mt) | ((uint32_t)((th % g.cH) * g.mh) << 8) | ((uint32_t)vw << 20);
+                }
             } else
             a_o[h][i] = (uint32_t)((int64_t)(min(m0 + arow, g.M - 1) - m0) * g.lda * DT::ESIZE + ((scp ^ swz_a(srow)) << 4));
             const int lr = i * 64 + srow;                                   // LDS row of half-tile Bn<h>
@@ -441,15 +481,28 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         }
     const int wave_lds = wave * 1024;
     const char* a_tile = CONV ? reinterpret_cast<const char*>(g.A) : reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * DT::ESIZE;
-    const char* w_tile = reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * DT::ESIZE;
+    const char* w_tile = reinterpret_cast<const char*>(g.W) + ((int64_t)n0 + (SP ? (int64_t)sp_c * g.N : 0)) * g.ldw * DT::ESIZE;
     // conv mode: byte offsets of the CURRENT tap's source rows, one set per A half-tile stream (Am0 and Am1 are staged in
     // different phases for different K-tiles, so each stream crosses tap boundaries on its own)
     uint32_t tap_off[2][2] = {{0u, 0u}, {0u, 0u}};
     const uint32_t a_chunk = (uint32_t)((scp ^ swz_a(srow)) << 4);
     const int lg_cin = CONV ? 31 - __builtin_clz((unsigned)g.cin) : 0;       // cin is a power of two >= 256 here (host-side dispatch)
     auto conv_tap = [&](int h, int tap) {      // wave-uniform tap (dt, dh, dw): replicate / causal padding = the clamps, upsample = the halvings
-        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
         const uint32_t row_bytes = (uint32_t)g.lda * 2u;
+        if constexpr (SP) {
+            const uint32_t e = g.sp_tab[sp_c * g.sp_ntap + tap];      // wave-uniform: a scalar load, once per cin/64 K-tiles
+            const int ot = (int)(e & 15u) - 8, oh = (int)((e >> 4) & 15u) - 8, ow = (int)((e >> 8) & 15u) - 8;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t c = a_o[h][i];
+                const int ti = max((int)(c & 255u) + ot, 0);
+                const int hi = min(max((int)((c >> 8) & 4095u) + oh, 0), g.sH - 1);
+                const int wi = min(max((int)(c >> 20) + ow, 0), g.sW - 1);
+                tap_off[h][i] = (uint32_t)((ti * g.sH + hi) * g.sW + wi) * row_bytes + a_chunk;
+            }
+            return;
+        }
+        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const uint32_t c = a_o[h][i];
@@ -677,6 +730,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" : "+s"(ge.bias), "+s"(ge.gate), "+s"(ge.res), "+s"(ge.a_scale), "+s"(ge.w_scale), "+s"(ge.out0),
                  "+s"(ge.out1), "+s"(ge.out_f32) : : "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SP) {
+        ge.M = sp_M;
+        const SpRowMap rm{g.sH, g.sW, g.cH, g.cW, g.up_t, sp_pt, (sp_c >> 1) & 1, sp_c & 1};
+        gemm_epilogue<DT, 8, 4, 16, SpRowMap>(ge, acc, m0 + wm * 128 + fr, n0 + wn * 64, fq, rm);
+    } else
     gemm_epilogue<DT, 8, 4>(ge, acc, m0 + wm * 128 + fr, n0 + wn * 64, fq);
 }
 
@@ -687,6 +745,14 @@ int launch_gemm8(GemmArgs& g, hipStream_t stream) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + 255) / 256;
     gemm8_kernel<DT, CONV><<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS8_BYTES, stream>>>(g);
+    return hv_check_launch();
+}
+
+int launch_gemm8_subpixel(GemmArgs& g, hipStream_t stream) {      // g.tiles_m / sp_* filled by the caller
+    static HvPerDeviceOnce once;
+    if (hv_set_max_lds(once, (const void*)gemm8_kernel<F16T, true, true>, LDS8_BYTES) != HV_OK) return HV_ERR_LAUNCH;
+    g.tiles_n = (g.N + 255) / 256;
+    gemm8_kernel<F16T, true, true><<<dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS8_BYTES, stream>>>(g);
     return hv_check_launch();
 }
 
@@ -1261,6 +1327,42 @@ extern "C" int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_ta
     g.mt = g.mh = g.mw = 1; g.bH = H; g.bW = W;
     if ((int64_t)g.sT * g.sH * g.sW * ldx * 2 >= ((int64_t)1 << 32)) return HV_ERR_ARG;   // the gather uses 32-bit byte offsets (4 GiB source)
     return launch<F16T, true>(g, stream);
+}
+
+extern "C" int hv_conv3d_upsampled_subpixel_f16(const void* x, int64_t ldx, const void* w_sub, const void* tap_table, int ntap,
+                                               const void* bias, void* out, int64_t ldo, int sT, int sH, int sW, int Cin, int Cout,
+                                               int up_t, hipStream_t stream) {
+    // (nearest upsample x2 in H, W [and causally in T: 2 sT - 1 frames] -> causal 3x3x3 conv) in its sub-pixel form: the outputs of one
+    // parity class (t, h, w mod 2) see each source voxel through a fixed set of taps, so the class is a conv over the SOURCE grid with
+    // 2 (pre-summed) taps per upsampled axis - 8 (or 3*2*2 = 12) taps instead of 27.  x: channels-last source [sT, sH, sW, >= Cin];
+    // out: channels-last [T2, 2 sH, 2 sW, Cout]; w_sub: [classes][Cout][ntap * Cin] f16, classes = 8 (up_t; index pt*4 + ph*2 + pw) or
+    // 4 (ph*2 + pw); tap_table (device, int32 [classes][ntap]): source offset of each tap of each class, (ot+8) | (oh+8)<<4 | (ow+8)<<8.
+    // The caller builds weights and table (vae_ops.subpixel_weights): which taps are summed, and whether the rounding residue of a
+    // sum is carried as an extra "lo" tap, is its choice - this kernel only needs offsets.
+    if (!x || !w_sub || !tap_table || !out || sT <= 0 || sH <= 0 || sW <= 0 || ntap < 1 || ntap > 27 || (up_t & ~1)) return HV_ERR_ARG;
+    if (Cin < 256 || (Cin & (Cin - 1)) || Cout <= 128 || (Cout & 7)) return HV_ERR_ARG;       // the pipelined conv tile's shapes
+    const int T2 = up_t ? 2 * sT - 1 : sT, H2 = 2 * sH, W2 = 2 * sW, ncls = up_t ? 8 : 4;
+    if ((int64_t)T2 * H2 * W2 > 0x7fffffff || sT + 1 >= 256 || sH > 4096 || sW > 4096) return HV_ERR_ARG;
+    GemmArgs g;
+    int rc = fill_common(g, x, ldx, w_sub, (int64_t)ntap * Cin, bias, sT * sH * sW, Cout, ntap * Cin, out, ldo, 0, 0, nullptr, 0, 0,
+                         nullptr, nullptr, 0);
+    if (rc != HV_OK) return rc;
+    g.cT = T2; g.cH = H2; g.cW = W2; g.cin = Cin; g.up_t = up_t; g.up_hw = 1;
+    g.sT = sT; g.sH = sH; g.sW = sW; g.mt = g.mh = g.mw = 1; g.bH = H2; g.bW = W2;
+    if ((int64_t)sT * sH * sW * ldx * 2 >= ((int64_t)1 << 32)) return HV_ERR_ARG;
+    g.sp_ntap = ntap; g.sp_tab = (const uint32_t*)tap_table;
+    int tiles = 0;
+    for (int c = 0; c < 8; ++c) {
+        const int frames = c >= ncls ? 0 : (up_t && (c >> 2)) ? sT - 1 : sT;       // odd output frames: 1, 3, .. 2 sT - 3
+        g.sp_tile0[c] = c < ncls ? tiles : 0x7fffffff;
+        g.sp_rows[c] = frames * sH * sW;
+        tiles += (g.sp_rows[c] + BM - 1) / BM;
+    }
+    g.sp_tile0[8] = tiles;
+    // an empty class (sT = 1: no odd frames) must not capture tiles: give it the start of its successor, which the class search skips past
+    if (tiles == 0) return HV_OK;
+    g.tiles_m = tiles;
+    return launch_gemm8_subpixel(g, stream);
 }
 
 extern "C" int hv_conv3d_causal_strided_f16(const void* x, int64_t ldx, const void* w_taps, const void* bias, void* out, int64_t ldo,

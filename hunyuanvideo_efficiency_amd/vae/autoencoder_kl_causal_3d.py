@@ -208,6 +208,19 @@ class AutoencoderKLCausal3D(nn.Module):
             bqkv = torch.cat([sd[a + n + ".bias"] for n in ("to_q", "to_k", "to_v")], 0)
             lin(a + "qkv", wqkv, bqkv)
             lin(a + "to_out.0", sd[a + "to_out.0.weight"], sd[a + "to_out.0.bias"])
+        # UpsampleCausal3D convs of the decoder in sub-pixel form (vae_ops.subpixel_weights): the 256- and 512-channel upsamplers
+        mode = V.subpixel_mode()
+        boc = self.config.block_out_channels
+        nb = len(boc)
+        for i in range(nb):
+            name = f"decoder.up_blocks.{i}.upsamplers.0.conv.conv"
+            sp, tm = i < 3, (i >= nb - 1 - 2) and (i != nb - 1)
+            if mode == "off" or name not in P or not sp:
+                continue
+            _, bp, cip, cop = P[name]
+            if cip >= 256 and (cip & (cip - 1)) == 0 and cop > 128:
+                w_sub, table, ntap = V.subpixel_weights(sd[name + ".weight"].to(dev), tm, mode, cip, cop)
+                P[name + "#subpixel"] = (w_sub, table, ntap, bp, cip, cop)
         self._prep = P
         return P
 
@@ -296,7 +309,12 @@ class AutoencoderKLCausal3D(nn.Module):
             tm = (i >= nb - 1 - 2) and (i != nb - 1)
             if sp or tm:
                 T2, H2, W2 = (1 + 2 * (T - 1) if tm else T), (2 * H if sp else H), (2 * W if sp else W)
-                h = self._conv(P, f"{pre}up_blocks.{i}.upsamplers.0.conv.conv", h, T2, H2, W2, up_t=tm, up_hw=sp)
+                name = f"{pre}up_blocks.{i}.upsamplers.0.conv.conv"
+                if name + "#subpixel" in P:
+                    w_sub, table, ntap, b, cip, cop = P[name + "#subpixel"]
+                    h = V.conv3d_upsampled_subpixel(h, w_sub, table, ntap, b, T, H, W, cip, cop, tm)
+                else:
+                    h = self._conv(P, name, h, T2, H2, W2, up_t=tm, up_hw=sp)
                 T, H, W = T2, H2, W2
         h = self._gn(P, pre + "conv_norm_out", h)
         out = self._conv(P, pre + "conv_out.conv", h, T, H, W)

@@ -64,6 +64,73 @@ def conv3d_causal(x, w_taps, bias, T: int, H: int, W: int, cin: int, cout: int, 
     return out
 
 
+def subpixel_mode() -> str:
+    """HV_VAE_SUBPIXEL = fast (default) | exact | off: how UpsampleCausal3D's conv runs, see subpixel_weights()."""
+    import os
+    m = os.environ.get("HV_VAE_SUBPIXEL", "fast")
+    if m not in ("fast", "exact", "off"):
+        raise ValueError(f"HV_VAE_SUBPIXEL={m!r}: expected fast, exact or off")
+    return m
+
+
+def subpixel_weights(w, up_t: bool, mode: str = "fast", cin_pad: Optional[int] = None, cout_pad: Optional[int] = None):
+    """Weights + tap table of hv_conv3d_upsampled_subpixel_f16 from a Conv3d weight w [Cout, Cin, 3, 3, 3].
+
+    Nearest x2 upsampling followed by a 3-tap conv along one axis reads, for an output of parity p, only two source samples:
+        H/W: p = 0:  w0 x[k-1] + (w1+w2) x[k]         p = 1: (w0+w1) x[k] + w2 x[k+1]
+        T  : p = 0:  w0 x[k-1] + (w1+w2) x[k]         p = 1: (w0+w1) x[k-1] + w2 x[k]   (k = kt + 1: frame 2k-1; first frame kept single)
+    (unet_causal_3d_blocks.py:154-172 + :49-75).  Per parity class the 27 taps collapse to 2x2x2 (3x2x2 if T is not upsampled).
+    The sums are formed in fp64 from the fp16 weights; `fast` rounds each to fp16 (the only difference from the 27-tap form: one
+    extra rounding of up to seven of eight weights, <= 2 fp16 ulp at the output), `exact` adds the rounding residue of every summed
+    weight as a second tap at the same offset (fp16 products are exact in the fp32 accumulator, so hi + lo reproduces the sum to
+    2^-22).  Returns (w_sub [classes, cout_pad, ntap*cin_pad] f16, table int32 [classes, ntap], ntap)."""
+    assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and mode in ("fast", "exact")
+    co, ci = w.shape[:2]
+    cip, cop = cin_pad or ci, cout_pad or co
+    w64 = w.detach().to(F16).to(torch.float64)
+    hw = {0: [(-1, (0,)), (0, (1, 2))], 1: [(0, (0, 1)), (1, (2,))]}
+    tt = {0: [(-1, (0,)), (0, (1, 2))], 1: [(-1, (0, 1)), (0, (2,))]} if up_t else {0: [(-2, (0,)), (-1, (1,)), (0, (2,))]}
+    classes = [(pt, ph, pw) for pt in sorted(tt) for ph in (0, 1) for pw in (0, 1)]
+    w_cls, t_cls = [], []
+    for pt, ph, pw in classes:
+        cols, offs = [], []
+        for ot, it in tt[pt]:
+            for oh, ih in hw[ph]:
+                for ow, iw in hw[pw]:
+                    acc = torch.zeros(co, ci, dtype=torch.float64, device=w.device)
+                    for a in it:
+                        for b in ih:
+                            for c in iw:
+                                acc += w64[:, :, a, b, c]
+                    hi = acc.to(F16)
+                    e = (ot + 8) | ((oh + 8) << 4) | ((ow + 8) << 8)
+                    cols.append(hi), offs.append(e)
+                    if mode == "exact" and len(it) * len(ih) * len(iw) > 1:
+                        cols.append((acc - hi.to(torch.float64)).to(F16)), offs.append(e)
+        wc = torch.zeros(cop, len(cols), cip, dtype=F16, device=w.device)
+        wc[:co, :, :ci] = torch.stack(cols, 1)
+        w_cls.append(wc.reshape(cop, -1)), t_cls.append(offs)
+    ntap = len(t_cls[0])
+    assert all(len(t) == ntap for t in t_cls)
+    table = torch.tensor(t_cls, dtype=torch.int32, device=w.device)
+    return torch.stack(w_cls, 0).contiguous(), table, ntap
+
+
+def conv3d_upsampled_subpixel(x, w_sub, table, ntap: int, bias, sT: int, sH: int, sW: int, cin: int, cout: int, up_t: bool, out=None):
+    """x: channels-last source rows [sT*sH*sW, >=cin] -> [T2*2sH*2sW, cout] fp16, T2 = 2 sT - 1 if up_t else sT."""
+    _chk(x, F16, "x"), _chk(w_sub, F16, "w_sub"), _chk(table, torch.int32, "tap_table")
+    _conv_source_limit(x)
+    ncls = 8 if up_t else 4
+    assert w_sub.is_contiguous() and tuple(w_sub.shape) == (ncls, cout, ntap * cin), (w_sub.shape, ncls, cout, ntap, cin)
+    assert table.is_contiguous() and tuple(table.shape) == (ncls, ntap)
+    T2 = 2 * sT - 1 if up_t else sT
+    if out is None:
+        out = torch.empty(T2 * 4 * sH * sW, cout, dtype=F16, device=x.device)
+    _lib.call("conv3d_upsampled_subpixel_f16", x, x.stride(0), w_sub, table, ntap, bias, out, out.stride(0), sT, sH, sW, cin, cout,
+              int(up_t))
+    return out
+
+
 def conv3d_causal_strided(x, w_taps, bias, sT: int, sH: int, sW: int, cin: int, cout: int, stride=(1, 1, 1)):
     """DownsampleCausal3D conv: x channels-last [sT*sH*sW, >=cin] -> ([T*H*W, cout] fp16, T, H, W)."""
     _chk(x, F16, "x"), _chk(w_taps, F16, "w_taps")

@@ -172,6 +172,22 @@ int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_taps, const v
                          int T, int H, int W, int Cin, int Cout, int up_t, int up_hw, const void* res,
                          int64_t ld_res, hipStream_t stream);
 
+/* UpsampleCausal3D (unet_causal_3d_blocks.py:154-172: nearest x2 in H, W - and in T with the first frame kept single - then the
+ * causal 3x3x3 conv) in its SUB-PIXEL form.  The outputs of one parity class (t, h, w mod 2) read every source voxel through a
+ * fixed subset of the 27 taps, so each class is a conv over the SOURCE grid with 2 pre-summed taps per upsampled axis:
+ *     H/W, even output 2k:   w0 x[k-1] + (w1+w2) x[k]        odd output 2k+1: (w0+w1) x[k] + w2 x[k+1]      (indices clamped = replicate pad)
+ *     T,   even frame  2k:   w0 x[k-1] + (w1+w2) x[k]        odd frame 2k-1:  (w0+w1) x[k-1] + w2 x[k]      (k-1 clamped at 0 = causal pad)
+ * 8 taps (12 when only H, W are upsampled) instead of 27: 3.4x (2.25x) fewer flops than hv_conv3d_causal_f16 with up_t/up_hw, and
+ * algebraically the same function.  x: source [sT,sH,sW,Cin]; out: [T2, 2 sH, 2 sW, Cout], T2 = 2 sT - 1 (up_t) or sT;
+ * w_sub: [classes][Cout][ntap*Cin] fp16, class = pt*4 + ph*2 + pw (8, up_t) or ph*2 + pw (4); tap_table: device int32
+ * [classes][ntap], source offset of each tap as (ot+8) | (oh+8)<<4 | (ow+8)<<8.  Weights and table come from the caller
+ * (vae_ops.subpixel_weights): a summed weight is rounded to fp16 once ("fast": <= 2 fp16 ulp from the 27-tap form), or its rounding
+ * residue rides along as an extra tap with the same offset ("exact": products exact, as in the 27-tap form).
+ * Cin a power of two >= 256, Cout > 128 and % 8 == 0 (the decoder's 256- and 512-channel upsamplers). */
+int hv_conv3d_upsampled_subpixel_f16(const void* x, int64_t ldx, const void* w_sub, const void* tap_table, int ntap,
+                                     const void* bias, void* out, int64_t ldo, int sT, int sH, int sW, int Cin, int Cout,
+                                     int up_t, hipStream_t stream);
+
 /* DownsampleCausal3D (VAE encoder, unet_causal_3d_blocks.py:185-247): the same padding as hv_conv3d_causal_f16, then the 3x3x3
  * conv with stride 1|2 per axis (the fork's t_ops `downsample_stride` override, :737-742, changes these strides).
  * x: source [sT,sH,sW,Cin]; out: [T*H*W, Cout] with T = (sT-1)/stride_t + 1, H = (sH-1)/stride_h + 1, W likewise. */

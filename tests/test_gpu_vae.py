@@ -112,6 +112,40 @@ def test_conv3d_with_fused_upsample(V, factor):
     torch.testing.assert_close(uncl(got, T2, H2, W2), ref, rtol=2e-3, atol=2e-3)
 
 
+# UpsampleCausal3D in sub-pixel form (hv_conv3d_upsampled_subpixel_f16): 8 (or 12) pre-summed taps per output parity class
+# instead of 27 on the upsampled grid.  Oracle: nearest upsample + causal conv, unet_causal_3d_blocks.py:154-172 + :49-75.
+# Tolerance: the conv tests' rtol = atol = 2e-3 for both modes; `exact` (rounding residues carried as extra taps) must also agree
+# with the 27-tap kernel to fp32-summation-order noise (<= 1 fp16 ulp on a few outputs), `fast` within 2 fp16 ulp.
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+@pytest.mark.parametrize("factor,thw,C", [((2, 2, 2), (3, 5, 6), 256), ((1, 2, 2), (2, 9, 7), 256), ((2, 2, 2), (1, 4, 4), 256),
+                                          ((2, 2, 2), (2, 3, 20), 512)])
+def test_conv3d_upsampled_subpixel(V, factor, thw, C, mode):
+    T, H, W = thw
+    up_t = factor[0] == 2
+    x = E.r(U((1, C, T, H, W), "sp.x"))
+    w = E.r(U((C, C, 3, 3, 3), "sp.w", 1 / math.sqrt(27 * C)))
+    b = E.r(U((C,), "sp.b", 0.1))
+    up = R.upsample_causal(x, factor)
+    ref = R.causal_conv3d(up, w, b, E)
+    T2, H2, W2 = up.shape[2:]
+    w_sub, table, ntap = V.subpixel_weights(w.to(DEV), up_t, mode)
+    assert ntap == {("fast", True): 8, ("fast", False): 12, ("exact", True): 15, ("exact", False): 21}[(mode, up_t)]
+    got = V.conv3d_upsampled_subpixel(cl(x), w_sub, table, ntap, b.to(DEV).to(F16), T, H, W, C, C, up_t)
+    assert got.shape == (T2 * H2 * W2, C)
+    torch.testing.assert_close(uncl(got, T2, H2, W2), ref, rtol=2e-3, atol=2e-3)
+    direct = V.conv3d_causal(cl(x), taps(w), b.to(DEV).to(F16), T2, H2, W2, C, C, up_t=up_t, up_hw=True)
+    d = (got.float() - direct.float()).abs()
+    # fp16 spacing at |y|, floored at the tensor's mean magnitude: an output near zero is a cancelling sum whose error scales
+    # with its terms, not with the result
+    ulp = torch.clamp(direct.float().abs(), min=float(direct.float().abs().mean())) * 2.0 ** -10
+    if mode == "exact":
+        assert float((d / ulp).max()) <= 1.0 and float((d > 0).float().mean()) < 0.02, (float((d / ulp).max()), float((d > 0).float().mean()))
+    else:
+        assert float((d / ulp).max()) <= 3.0, float((d / ulp).max())
+    again = V.conv3d_upsampled_subpixel(cl(x), w_sub, table, ntap, b.to(DEV).to(F16), T, H, W, C, C, up_t)
+    assert torch.equal(got, again)
+
+
 @pytest.mark.parametrize("M_thw,C", [((3, 7, 5), 32), ((4, 16, 16), 128), ((2, 9, 9), 512)])
 def test_groupnorm_silu(V, M_thw, C):
     T, H, W = M_thw
@@ -173,6 +207,30 @@ def test_decoder_tile_vs_reference_golden(golden):
     ref16 = R.decode_tile(sd16, g["z"], boc, E)
     assert rel(y, ref16) < 5e-3, rel(y, ref16)          # vs oracle in the same fp16 contract
     assert rel(y, g["y"]) < 2e-2, rel(y, g["y"])         # vs the reference's fp32 output (fp16 drift bound)
+
+
+def test_full_topology_decoder_subpixel_modes(monkeypatch):
+    """Shipped topology (128, 256, 512, 512): the three upsamplers take the sub-pixel kernel (`fast` is the default).  All three
+    settings of HV_VAE_SUBPIXEL against the oracle's decoder in the same fp16 contract (upsample, then 27-tap conv), and against each
+    other: `exact` reproduces the 27-tap decode to fp32-summation-order noise, `fast` to fp16-rounding level."""
+    boc = (128, 256, 512, 512)
+    z = syn.hashed_uniform((1, 16, 3, 6, 6), "sp.z", 0) * 1.7
+    ys = {}
+    for mode in ("off", "exact", "fast"):
+        monkeypatch.setenv("HV_VAE_SUBPIXEL", mode)
+        vae, sd16 = _vae(boc, 256, 64)
+        P = vae._prepare()
+        n_sub = sum(1 for k in P if k.endswith("#subpixel"))
+        assert n_sub == (0 if mode == "off" else 3)
+        ys[mode] = vae.decode(z.to(DEV), return_dict=False)[0].float().cpu()
+    assert ys["off"].shape == (1, 3, 9, 48, 48)
+    ref16 = R.decode_tile(sd16, z, boc, E)
+    for mode, y in ys.items():
+        assert rel(y, ref16) < 5e-3, (mode, rel(y, ref16))
+    assert rel(ys["exact"], ys["off"]) < 2e-3, rel(ys["exact"], ys["off"])
+    assert rel(ys["fast"], ys["off"]) < 5e-3, rel(ys["fast"], ys["off"])
+    mean_err = {m: float((ys[m] - ref16).abs().mean() / ref16.abs().max()) for m in ys}
+    assert mean_err["fast"] < 1.5 * mean_err["off"] + 1e-5, mean_err      # no systematic error: the mean stays at rounding level
 
 
 def test_tiled_decode_vs_reference_golden(golden):
