@@ -227,10 +227,13 @@ def test_full_topology_decoder_subpixel_modes(monkeypatch):
     ref16 = R.decode_tile(sd16, z, boc, E)
     for mode, y in ys.items():
         assert rel(y, ref16) < 5e-3, (mode, rel(y, ref16))
-    assert rel(ys["exact"], ys["off"]) < 2e-3, rel(ys["exact"], ys["off"])
+    # ~30 fp16 layers deep a single rounding flip is amplified (cf. the tiled-decode test below), so the max-norm distance between
+    # two correct decodes is of the same order as each one's distance to the oracle; the MEAN error is the sharper statement
+    assert rel(ys["exact"], ys["off"]) < 5e-3, rel(ys["exact"], ys["off"])
     assert rel(ys["fast"], ys["off"]) < 5e-3, rel(ys["fast"], ys["off"])
     mean_err = {m: float((ys[m] - ref16).abs().mean() / ref16.abs().max()) for m in ys}
-    assert mean_err["fast"] < 1.5 * mean_err["off"] + 1e-5, mean_err      # no systematic error: the mean stays at rounding level
+    print("mean |y - oracle| / max|oracle| per mode:", mean_err)
+    assert mean_err["exact"] < 1.25 * mean_err["off"] + 1e-5 and mean_err["fast"] < 1.5 * mean_err["off"] + 1e-5, mean_err
 
 
 def test_tiled_decode_vs_reference_golden(golden):
