@@ -17,7 +17,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhv_kernels.so")
 TORCH_OPS_PATH = os.path.join(_HERE, "lib", "libhv_torch_ops.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -46,12 +46,15 @@ SIGNATURES = {
     "hv_quant_rows_fp8": [_p, _l, _p, _l, _p, _l, _i, _p],
     "hv_gemm_fp8": [_p, _l, _p, _p, _l, _p, _p, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p, _p, _l, _p],
     "hv_gemm_f16": [_p, _l, _p, _l, _p, _i, _i, _i, _p, _l, _i, _p, _l, _p],
-    "hv_conv3d_causal_f16": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p],
+    "hv_conv3d_causal_f16": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p],
+    "hv_gn_partial_rows": [_l],
+    "hv_subpixel_gn_partial_rows": [_i, _i, _i, _i],
+    "hv_groupnorm_finalize_f16": [_p, _l, _l, _i, _i, _f, _p, _p, _p, _p],
     "hv_groupnorm_affine_f16": [_p, _l, _l, _i, _i, _f, _p, _p, _p, _l, _p, _p],
     "hv_groupnorm_apply_f16": [_p, _l, _p, _l, _l, _i, _p, _i, _p],
     "hv_softmax_rows_f32_f16": [_p, _l, _p, _l, _i, _i, _i, _f, _p],
     "hv_transpose_16b": [_p, _l, _p, _l, _i, _i, _p],
-    "hv_conv3d_upsampled_subpixel_f16": [_p, _l, _p, _p, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p],
+    "hv_conv3d_upsampled_subpixel_f16": [_p, _l, _p, _p, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p, _l, _p],
     "hv_conv3d_causal_strided_f16": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hv_temporal_resample_f16": [_p, _l, _p, _l, _i, _l, _i, _i, _i, _i, _p],
     "hv_vae_latent_tile_f16": [_p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _p, _p],
@@ -84,7 +87,7 @@ def load():
         except AttributeError as e:
             raise HVKernelError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name == "hv_attn_workspace_bytes" else C.c_int
+        fn.restype = C.c_int64 if name in ("hv_attn_workspace_bytes", "hv_gn_partial_rows", "hv_subpixel_gn_partial_rows") else C.c_int
     v = lib.hv_abi_version()
     if v != ABI_VERSION:
         raise HVKernelError(f"libhv_kernels ABI {v} != expected {ABI_VERSION}: rebuild the extension")

@@ -105,6 +105,9 @@ struct GemmArgs {
     // parity class c (sp_rows[c] class-local rows = source-grid voxels), weights [class][N][sp_ntap * cin], tap offsets from sp_tab
     int sp_tile0[9], sp_rows[8], sp_ntap;
     const uint32_t* sp_tab;   // [class][sp_ntap]: (ot + 8) | (oh + 8) << 4 | (ow + 8) << 8, source voxel = clamp(class voxel + offset)
+    // GroupNorm statistics of the OUTPUT, taken in the epilogue from the values it stores: gn_partial[b][n][2] = (sum, sum of squares)
+    // over the valid rows of 64-row block b (b = tile * 4 + wave row block), one writer per entry, fixed order: run-to-run identical
+    float* gn_partial;
 };
 
 // output row of class-local voxel m of parity class (pt, ph, pw): the class's voxels are the source grid (frames x sH x sW), output
@@ -136,7 +139,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // ---- epilogue shared by both main loops: lane holds, per (mi, n-repeat pair), 8 consecutive n of row m
 template <typename DT, int MREP, int NREP, int MSTEP = 16, typename RowMap = IdRowMap>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mrow0, int ncol0, int fq,
-                                              const RowMap& rowmap = RowMap()) {
+                                              const RowMap& rowmap = RowMap(), int gn_blk0 = 0) {
     auto unpack = [](const u32x4& w, float (&f)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -182,6 +185,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
         uint16_t* obase = second ? g.out1 + (n - g.n_split) : g.out0 + n;
         const int64_t ldo = second ? g.ld1 : g.ld0;
         const int act = second ? g.act1 : g.act0;
+        // GroupNorm statistics (fp16 outputs only): per 64-row block and per PAIR of adjacent columns, (sum, sum of squares) of the
+        // stored fp16 values by v_dot2_f32_f16 on the packed words the store uses - [0..3] sums, [4..7] squares of pairs 0..3
+        constexpr bool GN = std::is_same<DT, F16T>::value;
+        constexpr int NGB = MREP / 4;             // 64-row blocks this wave covers (4 m-repeats x 16 lanes each)
+        float gst[NGB][8];
+#pragma unroll
+        for (int bq = 0; bq < NGB; ++bq)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gst[bq][j] = 0.f;
 #pragma unroll
         for (int mi = 0; mi < MREP; ++mi) {
             const int m = mrow0 + mi * MSTEP;
@@ -221,6 +233,55 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
 #pragma unroll
             for (int i = 0; i < 4; ++i) w[i] = DT::pack(v[2 * i], v[2 * i + 1]);
             if (m < g.M) *reinterpret_cast<u32x4*>(obase + orow[mi] * ldo) = w;
+            if constexpr (GN) {
+                if (g.gn_partial && m < g.M) {
+                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                    const h2_t one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // (not __builtin_bit_cast(h2_t, w[i]): on an element of an ext_vector it reads element 0 for every i - hipcc 7.2)
+                        const uint32_t wi = w[i];
+                        h2_t hv;
+                        __builtin_memcpy(&hv, &wi, 4);
+                        gst[mi / 4][i] = __builtin_amdgcn_fdot2(hv, one, gst[mi / 4][i], false);
+                        gst[mi / 4][4 + i] = __builtin_amdgcn_fdot2(hv, hv, gst[mi / 4][4 + i], false);
+                    }
+                }
+            }
+        }
+        if constexpr (GN) {
+            if (g.gn_partial) {
+                // The 16 lanes that share fq hold the rows of these 8 columns (all 16 took the same `n < N` branch).  Butterfly
+                // transpose-reduction over lane bits 3..1: each step a lane keeps half of its values and receives the partner's copy
+                // of that half (8 -> 4 -> 2 -> 1 values), then one plain exchange over bit 0: 8 shuffles instead of 32.  Lane pair
+                // q = fr >> 1 ends up with value q = [square?][pair].  gn_partial[b][n .. n+7][2]: the pair's total goes to its
+                // even column, the odd column's slot is zero (a GroupNorm group holds whole pairs: C / groups is even).
+                const int fr_ = threadIdx.x & 15;
+#pragma unroll
+                for (int bq = 0; bq < NGB; ++bq) {
+                    float a4[4], a2[2], a1;
+                    const bool b3 = fr_ & 8, b2 = fr_ & 4, b1 = fr_ & 2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float keep = b3 ? gst[bq][4 + i] : gst[bq][i], send = b3 ? gst[bq][i] : gst[bq][4 + i];
+                        a4[i] = keep + __shfl_xor(send, 8, 64);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float keep = b2 ? a4[2 + i] : a4[i], send = b2 ? a4[i] : a4[2 + i];
+                        a2[i] = keep + __shfl_xor(send, 4, 64);
+                    }
+                    {
+                        const float keep = b1 ? a2[1] : a2[0], send = b1 ? a2[0] : a2[1];
+                        a1 = keep + __shfl_xor(send, 2, 64);
+                    }
+                    a1 += __shfl_xor(a1, 1, 64);
+                    // value held: square = b3, pair = 2*b2 + b1
+                    const int pair = (b2 ? 2 : 0) + (b1 ? 1 : 0);
+                    float* o = g.gn_partial + ((int64_t)(gn_blk0 + bq) * g.N + n + 2 * pair + (fr_ & 1)) * 2 + (b3 ? 1 : 0);
+                    *o = (fr_ & 1) ? 0.f : a1;
+                }
+            }
         }
     }
 }
@@ -390,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    gemm_epilogue<DT, 8, NREP>(g, acc, m0 + wm * 128 + fr, n0 + wn * (BN / 4), fq);
+    gemm_epilogue<DT, 8, NREP>(g, acc, m0 + wm * 128 + fr, n0 + wn * (BN / 4), fq, IdRowMap(), tm * 4 + wm * 2);
 }
 
 // =====================================================================================================================
@@ -728,14 +789,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         for (int ni = 0; ni < 4; ++ni) asm volatile("" : : "v"(acc[mi][ni]));     // a USE, not a redefinition: no effect on the loop's allocation
     GemmArgs ge = g;
     asm volatile("s_waitcnt vmcnt(0)" : "+s"(ge.bias), "+s"(ge.gate), "+s"(ge.res), "+s"(ge.a_scale), "+s"(ge.w_scale), "+s"(ge.out0),
-                 "+s"(ge.out1), "+s"(ge.out_f32) : : "memory");
+                 "+s"(ge.out1), "+s"(ge.out_f32), "+s"(ge.gn_partial) : : "memory");
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SP) {
         ge.M = sp_M;
         const SpRowMap rm{g.sH, g.sW, g.cH, g.cW, g.up_t, sp_pt, (sp_c >> 1) & 1, sp_c & 1};
-        gemm_epilogue<DT, 8, 4, 16, SpRowMap>(ge, acc, m0 + wm * 128 + fr, n0 + wn * 64, fq, rm);
+        gemm_epilogue<DT, 8, 4, 16, SpRowMap>(ge, acc, m0 + wm * 128 + fr, n0 + wn * 64, fq, rm, tm * 4 + wm * 2);
     } else
-    gemm_epilogue<DT, 8, 4>(ge, acc, m0 + wm * 128 + fr, n0 + wn * 64, fq);
+    gemm_epilogue<DT, 8, 4>(ge, acc, m0 + wm * 128 + fr, n0 + wn * 64, fq, IdRowMap(), tm * 4 + wm * 2);
 }
 
 template <typename DT, bool CONV = false>
@@ -939,9 +1000,9 @@ __global__ __launch_bounds__(512, 2) void conv128_kernel(GemmArgs g) {
         for (int ni = 0; ni < 4; ++ni) asm volatile("" : : "v"(acc[mi][ni]));
     GemmArgs ge = g;
     asm volatile("s_waitcnt vmcnt(0)" : "+s"(ge.bias), "+s"(ge.gate), "+s"(ge.res), "+s"(ge.a_scale), "+s"(ge.w_scale), "+s"(ge.out0),
-                 "+s"(ge.out1), "+s"(ge.out_f32) : : "memory");
+                 "+s"(ge.out1), "+s"(ge.out_f32), "+s"(ge.gn_partial) : : "memory");
     __builtin_amdgcn_sched_barrier(0);
-    gemm_epilogue<DT, 4, 4>(ge, acc, m0 + wm * 64 + fr, n0 + wn * 64, fq);
+    gemm_epilogue<DT, 4, 4>(ge, acc, m0 + wm * 64 + fr, n0 + wn * 64, fq, IdRowMap(), tm * 4 + wm);
 }
 
 int launch_conv128(GemmArgs& g, hipStream_t stream) {
@@ -1197,9 +1258,9 @@ __global__ __launch_bounds__(512, 2) void conv128s_kernel(GemmArgs g) {
         for (int ni = 0; ni < 4; ++ni) asm volatile("" : : "v"(acc[mi][ni]));
     GemmArgs ge = g;
     asm volatile("s_waitcnt vmcnt(0)" : "+s"(ge.bias), "+s"(ge.gate), "+s"(ge.res), "+s"(ge.a_scale), "+s"(ge.w_scale), "+s"(ge.out0),
-                 "+s"(ge.out1), "+s"(ge.out_f32) : : "memory");
+                 "+s"(ge.out1), "+s"(ge.out_f32), "+s"(ge.gn_partial) : : "memory");
     __builtin_amdgcn_sched_barrier(0);
-    gemm_epilogue<DT, 4, 4, 1>(ge, acc, m0 + wm * 64 + 4 * fr, wn * 64, fq);
+    gemm_epilogue<DT, 4, 4, 1>(ge, acc, m0 + wm * 64 + 4 * fr, wn * 64, fq, IdRowMap(), lin * 4 + wm);
 }
 
 int launch_conv128s(GemmArgs& g, hipStream_t stream) {
@@ -1312,7 +1373,7 @@ extern "C" int hv_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ld
 
 extern "C" int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_taps, const void* bias, void* out, int64_t ldo,
                                     int T, int H, int W, int Cin, int Cout, int up_t, int up_hw, const void* res,
-                                    int64_t ld_res, hipStream_t stream) {
+                                    int64_t ld_res, float* gn_partial, int64_t gn_partial_floats, hipStream_t stream) {
     // x: channels-last source [sT, sH, sW, >=Cin] (row stride ldx); output grid T x H x W (T = 1 + 2*(sT-1) when up_t,
     // H = 2*sH, W = 2*sW when up_hw); w_taps: [Cout][27][Cin] f16.
     if (T <= 0 || H <= 0 || W <= 0 || Cin < 64 || (Cin % 64) || Cout <= 0 || (up_t & ~1) || (up_hw & ~1)) return HV_ERR_ARG;
@@ -1326,12 +1387,24 @@ extern "C" int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_ta
     g.sT = up_t ? (T + 1) / 2 : T; g.sH = H >> up_hw; g.sW = W >> up_hw;
     g.mt = g.mh = g.mw = 1; g.bH = H; g.bW = W;
     if ((int64_t)g.sT * g.sH * g.sW * ldx * 2 >= ((int64_t)1 << 32)) return HV_ERR_ARG;   // the gather uses 32-bit byte offsets (4 GiB source)
+    if (gn_partial) {
+        if (gn_partial_floats < hv_gn_partial_rows(g.M) * (int64_t)Cout * 2) return HV_ERR_ARG;
+        g.gn_partial = gn_partial;
+    }
     return launch<F16T, true>(g, stream);
+}
+
+extern "C" int64_t hv_gn_partial_rows(int64_t M) { return 4 * ((M + BM - 1) / BM); }
+
+extern "C" int64_t hv_subpixel_gn_partial_rows(int sT, int sH, int sW, int up_t) {
+    int64_t tiles = 0;
+    for (int c = 0; c < (up_t ? 8 : 4); ++c) tiles += ((int64_t)((up_t && (c >> 2)) ? sT - 1 : sT) * sH * sW + BM - 1) / BM;
+    return tiles * 4;
 }
 
 extern "C" int hv_conv3d_upsampled_subpixel_f16(const void* x, int64_t ldx, const void* w_sub, const void* tap_table, int ntap,
                                                const void* bias, void* out, int64_t ldo, int sT, int sH, int sW, int Cin, int Cout,
-                                               int up_t, hipStream_t stream) {
+                                               int up_t, float* gn_partial, int64_t gn_partial_floats, hipStream_t stream) {
     // (nearest upsample x2 in H, W [and causally in T: 2 sT - 1 frames] -> causal 3x3x3 conv) in its sub-pixel form: the outputs of one
     // parity class (t, h, w mod 2) see each source voxel through a fixed set of taps, so the class is a conv over the SOURCE grid with
     // 2 (pre-summed) taps per upsampled axis - 8 (or 3*2*2 = 12) taps instead of 27.  x: channels-last source [sT, sH, sW, >= Cin];
@@ -1362,6 +1435,10 @@ extern "C" int hv_conv3d_upsampled_subpixel_f16(const void* x, int64_t ldx, cons
     // an empty class (sT = 1: no odd frames) must not capture tiles: give it the start of its successor, which the class search skips past
     if (tiles == 0) return HV_OK;
     g.tiles_m = tiles;
+    if (gn_partial) {
+        if (gn_partial_floats < (int64_t)tiles * 4 * Cout * 2) return HV_ERR_ARG;
+        g.gn_partial = gn_partial;
+    }
     return launch_gemm8_subpixel(g, stream);
 }
 

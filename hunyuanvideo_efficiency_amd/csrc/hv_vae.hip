@@ -83,46 +83,102 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restr
     }
 }
 
-// ---- GroupNorm pass 2 (one block): fold partials in fp64 -> per-channel affine y = x*sc[c] + sh[c]
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int groups,
+// ---- GroupNorm pass 2: fold the partials [nrow][C][2] in fp64 -> per-channel affine y = x*sc[c] + sh[c].  One block per group
+// (a single block folding all groups took 90-160 us on the large activations: more than the HBM pass over the activation it
+// follows); partial rows come from gn_partial_kernel (<= 1024 rows) or from a conv epilogue (one row per 64 output rows).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int64_t nrow, int C, int groups,
                                                            int64_t M, float eps, const uint16_t* __restrict__ w,
                                                            const uint16_t* __restrict__ b, float* __restrict__ affine) {
-    __shared__ double gs[64], gq[64];
-    const int cpg = C / groups;
-    const int tpg = 256 / groups;          // threads per group (groups is a power of two <= 64 -> tpg in 4..256)
-    {
-        const int g = threadIdx.x / tpg, sub = threadIdx.x % tpg;
-        double s = 0.0, q = 0.0;
-        for (int k = sub; k < nblk; k += tpg)
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-                s += (double)partial[((int64_t)k * C + c) * 2];
-                q += (double)partial[((int64_t)k * C + c) * 2 + 1];
+    __shared__ double ws[4], wq[4];
+    const int cpg = C / groups, g = blockIdx.x;
+    const float* p = partial + (int64_t)g * cpg * 2;
+    double s = 0.0, q = 0.0;
+    if ((cpg & 1) == 0) {
+        for (int64_t r = threadIdx.x; r < nrow; r += 256) {
+            const float4* row = reinterpret_cast<const float4*>(p + r * C * 2);       // cpg even, C*2 floats per row: 16-B aligned
+            float fs = 0.f, fq = 0.f;
+            for (int c = 0; c < cpg / 2; ++c) {
+                const float4 v = row[c];
+                fs += v.x + v.z;
+                fq += v.y + v.w;
             }
-        for (int o = (tpg < 64 ? tpg : 64) >> 1; o > 0; o >>= 1) {
-            s += __shfl_xor(s, o, 64);
-            q += __shfl_xor(q, o, 64);
+            s += (double)fs;
+            q += (double)fq;
         }
-        if (tpg <= 64) {
-            if (sub == 0) { gs[g] = s; gq[g] = q; }
-        } else {   // a group spans several waves: combine the wave leaders through LDS atomics-free two-step
-            __shared__ double ws[4], wq[4];
-            if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = s; wq[threadIdx.x >> 6] = q; }
-            __syncthreads();
-            if (sub == 0) {
-                double a = 0.0, bq = 0.0;
-                for (int i = 0; i < tpg / 64; ++i) { a += ws[g * (tpg / 64) + i]; bq += wq[g * (tpg / 64) + i]; }
-                gs[g] = a; gq[g] = bq;
+    } else {
+        for (int64_t r = threadIdx.x; r < nrow; r += 256)
+            for (int c = 0; c < cpg; ++c) {
+                s += (double)p[(r * C + c) * 2];
+                q += (double)p[(r * C + c) * 2 + 1];
             }
-        }
     }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = s; wq[threadIdx.x >> 6] = q; }
     __syncthreads();
+    s = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    q = (wq[0] + wq[1]) + (wq[2] + wq[3]);
     const double n = (double)M * cpg;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cpg;
-        const double mean = gs[g] / n;
-        double var = gq[g] / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = g * cpg + threadIdx.x; c < (g + 1) * cpg; c += 256) {
+        const float wc = h2f(w[c]), bc = h2f(b[c]);
+        affine[2 * c] = rstd * wc;
+        affine[2 * c + 1] = bc - (float)mean * rstd * wc;
+    }
+}
+
+// ---- the same fold in two levels for the long partial lists a conv epilogue leaves (one row per 64 output rows: 66,560 rows for the
+// 65 x 256 x 256 activations): block (g, s) folds every S-th 256-row slab of group g's columns into one fp64 pair, gn_finalize2 folds
+// the S pairs in index order.  Fixed assignment and order: run-to-run identical.
+__global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ partial, int64_t nrow, int C, int groups,
+                                                       double* __restrict__ tmp) {
+    __shared__ double ws[4], wq[4];
+    const int cpg = C / groups, g = blockIdx.x, S = gridDim.y;
+    const float* p = partial + (int64_t)g * cpg * 2;
+    double s = 0.0, q = 0.0;
+    for (int64_t r = (int64_t)blockIdx.y * 256 + threadIdx.x; r < nrow; r += (int64_t)S * 256) {
+        const float4* row = reinterpret_cast<const float4*>(p + r * C * 2);           // cpg even (host-checked): 16-B pieces
+        float fs = 0.f, fq = 0.f;
+        for (int c = 0; c < cpg / 2; ++c) {
+            const float4 v = row[c];
+            fs += v.x + v.z;
+            fq += v.y + v.w;
+        }
+        s += (double)fs;
+        q += (double)fq;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = s; wq[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tmp[((int64_t)g * S + blockIdx.y) * 2] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+        tmp[((int64_t)g * S + blockIdx.y) * 2 + 1] = (wq[0] + wq[1]) + (wq[2] + wq[3]);
+    }
+}
+
+__global__ __launch_bounds__(64) void gn_finalize2_kernel(const double* __restrict__ tmp, int S, int C, int groups, int64_t M, float eps,
+                                                           const uint16_t* __restrict__ w, const uint16_t* __restrict__ b,
+                                                           float* __restrict__ affine) {
+    const int cpg = C / groups, g = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < S; ++i) {          // every lane folds all S pairs in the same order: no cross-lane step, same bits in every lane
+        s += tmp[((int64_t)g * S + i) * 2];
+        q += tmp[((int64_t)g * S + i) * 2 + 1];
+    }
+    const double n = (double)M * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = g * cpg + threadIdx.x; c < (g + 1) * cpg; c += 64) {
         const float wc = h2f(w[c]), bc = h2f(b[c]);
         affine[2 * c] = rstd * wc;
         affine[2 * c + 1] = bc - (float)mean * rstd * wc;
@@ -331,8 +387,26 @@ extern "C" int hv_groupnorm_affine_f16(const void* x, int64_t ldx, int64_t M, in
     const int rows_per_blk = (int)((M + nblk - 1) / nblk);
     gn_partial_kernel<<<dim3(nblk), dim3(256), (size_t)nrl * C * 2 * sizeof(float), stream>>>((const uint16_t*)x, ldx, M, C,
                                                                                             partial_ws, rows_per_blk);
-    gn_finalize_kernel<<<dim3(1), dim3(256), 0, stream>>>(partial_ws, nblk, C, groups, M, eps, (const uint16_t*)weight,
-                                                          (const uint16_t*)bias, affine_out);
+    gn_finalize_kernel<<<dim3(groups), dim3(256), 0, stream>>>(partial_ws, nblk, C, groups, M, eps, (const uint16_t*)weight,
+                                                               (const uint16_t*)bias, affine_out);
+    return hv_check_launch();
+}
+
+extern "C" int hv_groupnorm_finalize_f16(const float* partial, int64_t nrow, int64_t M, int C, int groups, float eps,
+                                         const void* weight, const void* bias, float* affine_out, hipStream_t stream) {
+    // partial: [nrow][C][2] (sum, sum of squares) rows as written by a conv epilogue (hv_conv3d_causal_f16 `gn_partial`), followed by
+    // HV_GN_FOLD_WS_FLOATS floats of workspace; M = rows of the activation the statistics cover.  The epilogue credits a pair of
+    // adjacent columns to the even one: a group must hold whole pairs.
+    if (!partial || !weight || !bias || !affine_out || nrow <= 0 || M <= 0 || C < 8 || (C & 7) || C > 2048 || groups <= 0 ||
+        groups > 64 || (groups & (groups - 1)) || (C % groups) || ((C / groups) & 1))
+        return HV_ERR_ARG;
+    int S = (int)((nrow + 1023) / 1024);                                     // >= 4 rows per thread and slab set
+    if (S > HV_GN_FOLD_WS_FLOATS / (64 * 4)) S = HV_GN_FOLD_WS_FLOATS / (64 * 4);       // groups <= 64, 2 doubles = 4 floats each
+    if (S < 1) S = 1;
+    double* tmp = reinterpret_cast<double*>(const_cast<float*>(partial) + ((nrow * C * 2 + 1) & ~(int64_t)1));
+    gn_fold_kernel<<<dim3(groups, S), dim3(256), 0, stream>>>(partial, nrow, C, groups, tmp);
+    gn_finalize2_kernel<<<dim3(groups), dim3(64), 0, stream>>>(tmp, S, C, groups, M, eps, (const uint16_t*)weight,
+                                                               (const uint16_t*)bias, affine_out);
     return hv_check_launch();
 }
 

@@ -235,22 +235,33 @@ class AutoencoderKLCausal3D(nn.Module):
         V.copy4d_(x[None, None], xp[None, None, :, :x.shape[1]])
         return xp
 
-    def _conv(self, P, name, x, T, H, W, up_t=False, up_hw=False, res=None):
+    def _conv(self, P, name, x, T, H, W, up_t=False, up_hw=False, res=None, gn_stats=False):
+        """gn_stats: also return the GroupNorm(32) statistics of the output, taken in the conv's epilogue (None where the epilogue's
+        pairwise bookkeeping does not apply: an odd number of channels per group - reduced test models only)."""
         wt, b, cip, cop = P[name]
-        return V.conv3d_causal(self._pad_channels(x, cip), wt, b, T, H, W, cip, cop, up_t, up_hw, res)
+        if gn_stats and (cop % 64):
+            return V.conv3d_causal(self._pad_channels(x, cip), wt, b, T, H, W, cip, cop, up_t, up_hw, res), None
+        return V.conv3d_causal(self._pad_channels(x, cip), wt, b, T, H, W, cip, cop, up_t, up_hw, res, gn_stats=gn_stats)
 
-    def _gn(self, P, name, x, silu=True):
+    def _gn(self, P, name, x, silu=True, stats=None):
+        """GroupNorm(32) [+ SiLU].  `stats`: the statistics of x if the conv that produced it took them in its epilogue
+        (vae_ops.GNStats) - then no pass over x is needed before the normalising one."""
         w, b = P[name]
+        if stats is not None:
+            assert stats.M == x.shape[0] and stats.C == x.shape[1], (stats.M, stats.C, x.shape)
+            return V.groupnorm_apply(x, V.groupnorm_affine_from_stats(stats, w, b, 32, 1e-6), silu)
         return V.groupnorm_apply(x, V.groupnorm_affine(x, w, b, 32, 1e-6), silu)
 
-    def _resnet(self, P, pre, x, T, H, W):
-        h = self._gn(P, pre + "norm1", x)
-        h = self._conv(P, pre + "conv1.conv", h, T, H, W)
-        h = self._gn(P, pre + "norm2", h)
+    def _resnet(self, P, pre, x, T, H, W, x_stats=None, out_stats=False):
+        """ResnetBlockCausal3D (unet_causal_3d_blocks.py:395-415).  x_stats: GroupNorm statistics of x if its producer took them;
+        out_stats: return (y, statistics of y) for the GroupNorm that consumes y next."""
+        h = self._gn(P, pre + "norm1", x, stats=x_stats)
+        h, st = self._conv(P, pre + "conv1.conv", h, T, H, W, gn_stats=True)
+        h = self._gn(P, pre + "norm2", h, stats=st)
         if (pre + "conv_shortcut.conv") in P:
             ws, bs = P[pre + "conv_shortcut.conv"]
             x = V.gemm_f16(self._pad_channels(x, ws.shape[1]), ws, bs, k=ws.shape[1])
-        return self._conv(P, pre + "conv2.conv", h, T, H, W, res=x)
+        return self._conv(P, pre + "conv2.conv", h, T, H, W, res=x, gn_stats=out_stats)
 
     def _mid_attention(self, P, pre, x, T, HW):
         L, C = x.shape
@@ -290,6 +301,7 @@ class AutoencoderKLCausal3D(nn.Module):
         boc = self.config.block_out_channels
         nb = len(boc)
         n_res = self.config.layers_per_block + 1
+        st = None          # GroupNorm statistics of h, when the conv that produced h took them
         for i in range(nb):
             bc = self._block_cfg(dec_ops.get("up_blocks"), i) or {}
             eib = bc.get("enable_t_interp_before_block", [False] * n_res)
@@ -299,24 +311,33 @@ class AutoencoderKLCausal3D(nn.Module):
             sc = int(bc.get("interp_t_scale_factor", 2))
             if (any(eib) or any(eia)) and bc.get("interp_mode", "nearest") != "nearest":
                 raise NotImplementedError("t_ops interp_mode: only 'nearest' has a kernel (the fork's config default)")
+            sp = i < 3
+            tm = (i >= nb - 1 - 2) and (i != nb - 1)
             for j in range(n_res):
                 if eib[j]:
                     h, T = V.temporal_nearest_up(h, T, H * W, sc)      # unet_causal_3d_blocks.py:884-895
-                h = self._resnet(P, f"{pre}up_blocks.{i}.resnets.{j}.", h, T, H, W)
+                    st = None
+                # the tensor this resnet returns is normalised next (the following resnet's norm1, or conv_norm_out after the last
+                # block) unless an upsampler or a t_ops interpolation comes in between: then its conv2 takes the statistics
+                feeds_gn = not eia[j] and (j + 1 < n_res and not eib[j + 1] or j + 1 == n_res and not (sp or tm))
+                h = self._resnet(P, f"{pre}up_blocks.{i}.resnets.{j}.", h, T, H, W, x_stats=st, out_stats=feeds_gn)
+                h, st = h if feeds_gn else (h, None)
                 if eia[j]:
                     h, T = V.temporal_nearest_up(h, T, H * W, sc)
-            sp = i < 3
-            tm = (i >= nb - 1 - 2) and (i != nb - 1)
             if sp or tm:
                 T2, H2, W2 = (1 + 2 * (T - 1) if tm else T), (2 * H if sp else H), (2 * W if sp else W)
                 name = f"{pre}up_blocks.{i}.upsamplers.0.conv.conv"
+                # the upsampler's output goes straight into the next block's first norm1
+                nxt = self._block_cfg(dec_ops.get("up_blocks"), i + 1) or {}
+                feeds_gn = i + 1 < nb and not nxt.get("enable_t_interp_before_block", [False])[0]
                 if name + "#subpixel" in P:
                     w_sub, table, ntap, b, cip, cop = P[name + "#subpixel"]
-                    h = V.conv3d_upsampled_subpixel(h, w_sub, table, ntap, b, T, H, W, cip, cop, tm)
+                    h = V.conv3d_upsampled_subpixel(h, w_sub, table, ntap, b, T, H, W, cip, cop, tm, gn_stats=feeds_gn)
                 else:
-                    h = self._conv(P, name, h, T2, H2, W2, up_t=tm, up_hw=sp)
+                    h = self._conv(P, name, h, T2, H2, W2, up_t=tm, up_hw=sp, gn_stats=feeds_gn)
+                h, st = h if feeds_gn else (h, None)
                 T, H, W = T2, H2, W2
-        h = self._gn(P, pre + "conv_norm_out", h)
+        h = self._gn(P, pre + "conv_norm_out", h, stats=st)
         out = self._conv(P, pre + "conv_out.conv", h, T, H, W)
         return out, T, H, W
 

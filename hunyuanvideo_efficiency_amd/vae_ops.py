@@ -47,9 +47,24 @@ def _conv_source_limit(x):
                          "call vae.enable_tiling() (the reference's default for decode) or decode/encode a smaller clip")
 
 
+class GNStats:
+    """GroupNorm statistics of an activation taken by the conv epilogue that stored it: `partial` fp32 [rows, C, 2]."""
+    __slots__ = ("partial", "rows", "M", "C")
+
+    def __init__(self, partial, rows, M, C):
+        self.partial, self.rows, self.M, self.C = partial, rows, M, C
+
+
+GN_FOLD_WS_FLOATS = 16384          # include/hv_kernels.h HV_GN_FOLD_WS_FLOATS: workspace hv_groupnorm_finalize_f16 expects behind the partials
+
+
+def _gn_stats_buffer(rows: int, c: int, device):
+    return torch.empty(rows * c * 2 + GN_FOLD_WS_FLOATS + 2, dtype=torch.float32, device=device)
+
+
 def conv3d_causal(x, w_taps, bias, T: int, H: int, W: int, cin: int, cout: int, up_t: bool = False, up_hw: bool = False,
-                  res=None, out=None):
-    """x: channels-last source rows [sT*sH*sW, >=cin]; returns [T*H*W, cout] fp16."""
+                  res=None, out=None, gn_stats: bool = False):
+    """x: channels-last source rows [sT*sH*sW, >=cin]; returns [T*H*W, cout] fp16 (with gn_stats: (out, GNStats))."""
     _chk(x, F16, "x"), _chk(w_taps, F16, "w_taps")
     _conv_source_limit(x)
     assert w_taps.is_contiguous() and w_taps.numel() == cout * 27 * cin, (w_taps.shape, cout, cin)
@@ -59,9 +74,13 @@ def conv3d_causal(x, w_taps, bias, T: int, H: int, W: int, cin: int, cout: int, 
     if res is not None:
         _chk(res, F16, "res")
         ld_res = res.stride(0)
+    st = None
+    if gn_stats:
+        rows = _lib.host("gn_partial_rows", T * H * W)
+        st = GNStats(_gn_stats_buffer(rows, cout, x.device), rows, T * H * W, cout)
     _lib.call("conv3d_causal_f16", x, x.stride(0), w_taps, bias, out, out.stride(0), T, H, W,
-                                                cin, cout, int(up_t), int(up_hw), res, ld_res)
-    return out
+              cin, cout, int(up_t), int(up_hw), res, ld_res, st.partial if st else None, st.partial.numel() if st else 0)
+    return (out, st) if gn_stats else out
 
 
 def subpixel_mode() -> str:
@@ -116,7 +135,8 @@ def subpixel_weights(w, up_t: bool, mode: str = "fast", cin_pad: Optional[int] =
     return torch.stack(w_cls, 0).contiguous(), table, ntap
 
 
-def conv3d_upsampled_subpixel(x, w_sub, table, ntap: int, bias, sT: int, sH: int, sW: int, cin: int, cout: int, up_t: bool, out=None):
+def conv3d_upsampled_subpixel(x, w_sub, table, ntap: int, bias, sT: int, sH: int, sW: int, cin: int, cout: int, up_t: bool, out=None,
+                              gn_stats: bool = False):
     """x: channels-last source rows [sT*sH*sW, >=cin] -> [T2*2sH*2sW, cout] fp16, T2 = 2 sT - 1 if up_t else sT."""
     _chk(x, F16, "x"), _chk(w_sub, F16, "w_sub"), _chk(table, torch.int32, "tap_table")
     _conv_source_limit(x)
@@ -126,9 +146,13 @@ def conv3d_upsampled_subpixel(x, w_sub, table, ntap: int, bias, sT: int, sH: int
     T2 = 2 * sT - 1 if up_t else sT
     if out is None:
         out = torch.empty(T2 * 4 * sH * sW, cout, dtype=F16, device=x.device)
+    st = None
+    if gn_stats:
+        rows = _lib.host("subpixel_gn_partial_rows", sT, sH, sW, int(up_t))
+        st = GNStats(_gn_stats_buffer(rows, cout, x.device), rows, T2 * 4 * sH * sW, cout)
     _lib.call("conv3d_upsampled_subpixel_f16", x, x.stride(0), w_sub, table, ntap, bias, out, out.stride(0), sT, sH, sW, cin, cout,
-              int(up_t))
-    return out
+              int(up_t), st.partial if st else None, st.partial.numel() if st else 0)
+    return (out, st) if gn_stats else out
 
 
 def conv3d_causal_strided(x, w_taps, bias, sT: int, sH: int, sW: int, cin: int, cout: int, stride=(1, 1, 1)):
@@ -176,6 +200,14 @@ def groupnorm_affine(x, weight, bias, groups: int = 32, eps: float = 1e-6):
     aff = torch.empty(c, 2, dtype=torch.float32, device=x.device)
     _lib.call("groupnorm_affine_f16", x, x.stride(0), m, c, groups, eps, weight, bias, ws,
                                                    ws.numel(), aff)
+    return aff
+
+
+def groupnorm_affine_from_stats(st: GNStats, weight, bias, groups: int = 32, eps: float = 1e-6):
+    """The same affine from statistics a conv epilogue took (conv3d_causal(..., gn_stats=True)): no pass over the activation."""
+    _chk(weight, F16, "weight"), _chk(bias, F16, "bias")
+    aff = torch.empty(st.C, 2, dtype=torch.float32, device=st.partial.device)
+    _lib.call("groupnorm_finalize_f16", st.partial, st.rows, st.M, st.C, groups, eps, weight, bias, aff)
     return aff
 
 

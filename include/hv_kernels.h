@@ -167,10 +167,19 @@ int hv_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const vo
  * x(2,2,2)) that precedes its conv is folded into the gather.  x: source [sT,sH,sW,Cin] (row stride ldx);
  * w_taps: [Cout][27][Cin] fp16 (tap = (dt*3 + dh)*3 + dw); out: [T*H*W, Cout]; res (nullable): out = res + f16(y)
  * (ResnetBlockCausal3D residual :413-415).  Cin % 64 == 0, Cout % 8 == 0 (callers zero-pad 16->64 and 3->8).
- * The source is addressed with 32-bit byte offsets: sT*sH*sW*ldx*2 must be < 4 GiB (HV_ERR_ARG otherwise). */
+ * The source is addressed with 32-bit byte offsets: sT*sH*sW*ldx*2 must be < 4 GiB (HV_ERR_ARG otherwise).
+ * gn_partial (nullable, device fp32 [hv_gn_partial_rows(T*H*W)][Cout][2], gn_partial_floats = its size): the epilogue also
+ * leaves the GroupNorm statistics of the tensor it stores - (sum, sum of squares) per channel over each 64-row block, every entry
+ * written once, in a fixed order - so the GroupNorm that follows (ResnetBlockCausal3D.norm1/norm2 :395-411, conv_norm_out) needs no
+ * pass over the activation: hv_groupnorm_finalize_f16 folds them.  HV_ERR_ARG if the buffer is too small. */
 int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_taps, const void* bias, void* out, int64_t ldo,
                          int T, int H, int W, int Cin, int Cout, int up_t, int up_hw, const void* res,
-                         int64_t ld_res, hipStream_t stream);
+                         int64_t ld_res, float* gn_partial, int64_t gn_partial_floats, hipStream_t stream);
+
+/* rows of the gn_partial buffer for an output of M rows: one per 64 output rows, whole 256-row tiles. */
+int64_t hv_gn_partial_rows(int64_t M);
+/* ... and for hv_conv3d_upsampled_subpixel_f16, whose M tiles are formed per parity class (some blocks cover no row: zeros). */
+int64_t hv_subpixel_gn_partial_rows(int sT, int sH, int sW, int up_t);
 
 /* UpsampleCausal3D (unet_causal_3d_blocks.py:154-172: nearest x2 in H, W - and in T with the first frame kept single - then the
  * causal 3x3x3 conv) in its SUB-PIXEL form.  The outputs of one parity class (t, h, w mod 2) read every source voxel through a
@@ -183,10 +192,11 @@ int hv_conv3d_causal_f16(const void* x, int64_t ldx, const void* w_taps, const v
  * [classes][ntap], source offset of each tap as (ot+8) | (oh+8)<<4 | (ow+8)<<8.  Weights and table come from the caller
  * (vae_ops.subpixel_weights): a summed weight is rounded to fp16 once ("fast": <= 2 fp16 ulp from the 27-tap form), or its rounding
  * residue rides along as an extra tap with the same offset ("exact": products exact, as in the 27-tap form).
- * Cin a power of two >= 256, Cout > 128 and % 8 == 0 (the decoder's 256- and 512-channel upsamplers). */
+ * Cin a power of two >= 256, Cout > 128 and % 8 == 0 (the decoder's 256- and 512-channel upsamplers).
+ * gn_partial: as for hv_conv3d_causal_f16, [hv_subpixel_gn_partial_rows(sT, sH, sW, up_t)][Cout][2]. */
 int hv_conv3d_upsampled_subpixel_f16(const void* x, int64_t ldx, const void* w_sub, const void* tap_table, int ntap,
                                      const void* bias, void* out, int64_t ldo, int sT, int sH, int sW, int Cin, int Cout,
-                                     int up_t, hipStream_t stream);
+                                     int up_t, float* gn_partial, int64_t gn_partial_floats, hipStream_t stream);
 
 /* DownsampleCausal3D (VAE encoder, unet_causal_3d_blocks.py:185-247): the same padding as hv_conv3d_causal_f16, then the 3x3x3
  * conv with stride 1|2 per axis (the fork's t_ops `downsample_stride` override, :737-742, changes these strides).
@@ -207,6 +217,14 @@ int hv_temporal_resample_f16(const void* x, int64_t ldx, void* out, int64_t ldo,
 int hv_groupnorm_affine_f16(const void* x, int64_t ldx, int64_t M, int C, int groups, float eps, const void* weight,
                             const void* bias, float* partial_ws, int64_t partial_ws_floats, float* affine_out,
                             hipStream_t stream);
+
+/* K16 pass 2 alone: the same affine from statistics a conv epilogue already took (hv_conv3d_causal_f16 `gn_partial`):
+ * partial [nrow][C][2] fp32 followed by HV_GN_FOLD_WS_FLOATS floats of workspace (the buffer a conv was given must be that much
+ * longer than the conv itself requires), M = rows of the activation they cover.  Folded in fp64 in a fixed order.  The epilogue
+ * credits each pair of adjacent channels to the even one, so C / groups must be even (HV_ERR_ARG otherwise). */
+#define HV_GN_FOLD_WS_FLOATS 16384
+int hv_groupnorm_finalize_f16(const float* partial, int64_t nrow, int64_t M, int C, int groups, float eps, const void* weight,
+                              const void* bias, float* affine_out, hipStream_t stream);
 
 /* K16 pass 3: y = [SiLU](x*affine[2c] + affine[2c+1]) -> fp16 (norm + nonlinearity, unet_causal_3d_blocks.py:361-363,399-405). */
 int hv_groupnorm_apply_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int C, const float* affine,

@@ -159,6 +159,46 @@ def test_groupnorm_silu(V, M_thw, C):
         torch.testing.assert_close(uncl(got, T, H, W), ref, rtol=2e-3, atol=2e-3)
 
 
+# GroupNorm statistics taken in the conv epilogue (hv_conv3d_causal_f16 `gn_partial`) against the separate pass over the stored
+# tensor (hv_groupnorm_affine_f16): same affine.  Shapes chosen to go through every conv main loop that shares the epilogue:
+# 2-stage (Cin 64), pipelined 256x128 per-tap (W = 12) and shift-reuse (W = 16), pipelined 256x256 (Cin = Cout = 256); ragged
+# last tile, residual epilogue, Cout below a full N tile.
+@pytest.mark.parametrize("T,H,W,Cin,Cout,with_res", [(3, 6, 5, 64, 64, False), (2, 7, 12, 128, 128, True), (3, 5, 16, 128, 64, False),
+                                                     (2, 9, 16, 128, 128, True), (2, 6, 10, 256, 256, True), (1, 5, 7, 256, 512, False)])
+def test_conv_epilogue_groupnorm_statistics(V, T, H, W, Cin, Cout, with_res):
+    x = E.r(U((1, Cin, T, H, W), "gs.x"))
+    w = E.r(U((Cout, Cin, 3, 3, 3), "gs.w", 1 / math.sqrt(27 * Cin)))
+    b = E.r(U((Cout,), "gs.b", 0.1))
+    res = cl(E.r(U((1, Cout, T, H, W), "gs.res"))) if with_res else None
+    gw, gb = (1 + U((Cout,), "gs.gw", 0.1)).to(DEV).to(F16), U((Cout,), "gs.gb", 0.1).to(DEV).to(F16)
+    plain = V.conv3d_causal(cl(x), taps(w), b.to(DEV).to(F16), T, H, W, Cin, Cout, res=res)
+    out, st = V.conv3d_causal(cl(x), taps(w), b.to(DEV).to(F16), T, H, W, Cin, Cout, res=res, gn_stats=True)
+    assert torch.equal(out, plain) and st.M == T * H * W and st.C == Cout
+    a_sep = V.groupnorm_affine(out, gw, gb)
+    a_fused = V.groupnorm_affine_from_stats(st, gw, gb)
+    torch.testing.assert_close(a_fused, a_sep, rtol=2e-5, atol=2e-6)
+    # and against the definition, from the stored fp16 tensor in fp64
+    o = out.double().reshape(T * H * W, 32, Cout // 32)
+    mean, var = o.mean((0, 2)), o.var((0, 2), unbiased=False)
+    rstd = (1.0 / torch.sqrt(var + 1e-6)).repeat_interleave(Cout // 32)
+    sc = rstd * gw.double()
+    sh = gb.double() - mean.repeat_interleave(Cout // 32) * sc
+    torch.testing.assert_close(a_fused.double(), torch.stack([sc, sh], 1), rtol=1e-4, atol=1e-5)
+
+
+def test_subpixel_conv_groupnorm_statistics(V):
+    T, H, W, C = 3, 5, 6, 256
+    x = E.r(U((1, C, T, H, W), "gsp.x"))
+    w = E.r(U((C, C, 3, 3, 3), "gsp.w", 1 / math.sqrt(27 * C)))
+    b = E.r(U((C,), "gsp.b", 0.1)).to(DEV).to(F16)
+    gw, gb = (1 + U((C,), "gsp.gw", 0.1)).to(DEV).to(F16), U((C,), "gsp.gb", 0.1).to(DEV).to(F16)
+    for up_t in (True, False):
+        w_sub, table, ntap = V.subpixel_weights(w.to(DEV), up_t, "fast")
+        out, st = V.conv3d_upsampled_subpixel(cl(x), w_sub, table, ntap, b, T, H, W, C, C, up_t, gn_stats=True)
+        assert st.M == out.shape[0]
+        torch.testing.assert_close(V.groupnorm_affine_from_stats(st, gw, gb), V.groupnorm_affine(out, gw, gb), rtol=2e-5, atol=2e-6)
+
+
 def test_gemm_f16_softmax_transpose(V):
     a, w, b = E.r(U((300, 128), "gf.a")), E.r(U((72, 128), "gf.w", 0.1)), E.r(U((72,), "gf.b", 0.1))
     ref = a @ w.T + b
