@@ -190,14 +190,28 @@ class UlyssesLongContextAttention:
         self._full_bufs(n_tot, w, device)
         self._works = []
 
+    def chunk_dst(self, which: str) -> Optional[torch.Tensor]:
+        """Where the caller may PRODUCE the local q / k / v chunk so that send() has nothing to move: with a Ulysses group of one
+        rank there is no exchange, and the chunk's rows are simply rows [0, s_loc) of this rank's attention operand (a [s_loc, H*128]
+        view, row stride H*128).  None when the chunk has to be packed per peer (P > 1)."""
+        P, rank, s_loc, n_j, heads, w = self._geo
+        if P != 1:
+            return None
+        return self._bufs[{"q": "qf", "k": "kf", "v": "vf"}[which]][:s_loc]
+
     def send(self, which: str, src: torch.Tensor, ld_src: int, joint: Optional[torch.Tensor], ld_j: int):
         """src: view whose data_ptr is (local image row 0, head 0) of the q / k / v chunk; joint: same for the valid text rows."""
         P, rank, s_loc, n_j, heads, w = self._geo
         name = {"q": "qf", "k": "kf", "v": "vf"}[which]
         full = self._bufs[name]
-        send = self._buf("send_" + which, (P * s_loc, w), src.device)      # one send buffer per tensor: exchanges overlap
-        self.k.copy3d(src, send, P, s_loc, w, w, ld_src, s_loc * w, w)
-        self._works.append(dist.all_to_all_single(full[:P * s_loc], send, group=self.group, async_op=True))
+        if P == 1:
+            # one rank: the "exchange" is the identity.  Produced in place (chunk_dst) -> nothing to do; otherwise one copy
+            if src.data_ptr() != full.data_ptr():
+                self.k.copy3d(src, full, 1, s_loc, w, 0, ld_src, 0, w)
+        else:
+            send = self._buf("send_" + which, (P * s_loc, w), src.device)      # one send buffer per tensor: exchanges overlap
+            self.k.copy3d(src, send, P, s_loc, w, w, ld_src, s_loc * w, w)
+            self._works.append(dist.all_to_all_single(full[:P * s_loc], send, group=self.group, async_op=True))
         if n_j:
             self.k.copy3d(joint[:, rank * w:], full[P * s_loc:], 1, n_j, w, 0, ld_j, 0, w)
 
@@ -222,6 +236,11 @@ class UlyssesLongContextAttention:
         self._works = []
         b = self._bufs
         s_img = P * s_loc
+        if P == 1 and out.dim() == 2 and out.shape[0] >= s_loc + n_j and out.shape[1] >= w and out.stride(0) == ld_out:
+            # one rank: every output row is already this rank's - attention writes straight into the caller's rows (no staging
+            # buffer, no unpack); one segment, nothing to wait for
+            self._attention({"qf": b["qf"], "kf": b["kf"], "vf": b["vf"], "of": out[:s_loc + n_j, :w]}, heads, s_img, n_j)
+            return [(0, s_loc + n_j, lambda: None)]
         self._attention(b, heads // P, s_img, n_j)
         of = b["of"]
         recv = self._buf("recv", (s_img, w), out.device)

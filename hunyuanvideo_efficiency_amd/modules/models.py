@@ -102,12 +102,15 @@ def _sp_chunked_qkv(sp, ws: _Workspace, layer, fp8, q_norm_w, k_norm_w, cos, sin
     ld = ws.qkv.stride(0)
     sp.begin(s_img, cu1 - s_img, H, ws.qkv.device)
     for c, which, norm_w in ((0, "q", q_norm_w), (1, "k", k_norm_w), (2, "v", None)):
-        chunk = ws.qkv[:s_img, c * d:(c + 1) * d]
+        # where the chunk is produced: the Ulysses object's own operand rows when it has nothing to exchange (one rank), else the
+        # fused-QKV workspace, from which send() packs it per peer
+        dst = sp.chunk_dst(which) if hasattr(sp, "chunk_dst") else None
+        chunk = dst if dst is not None else ws.qkv[:s_img, c * d:(c + 1) * d]
         _gemm(ws, layer, "xmod", 0, s_img, fp8, wrows=slice(c * d, (c + 1) * d), out=chunk)
         if norm_w is not None:
             # the kernel normalises 2 x (H/2) head vectors: with both halves given the same gain that is this chunk's H heads
             ops.qknorm_rope_(chunk, norm_w, norm_w, cos, sin, n_rope, H // 2, (H // 2) * 128)
-        sp.send(which, chunk, ld, ws.qkv[s_img:cu1, c * d:(c + 1) * d], ld)
+        sp.send(which, chunk, chunk.stride(0), ws.qkv[s_img:cu1, c * d:(c + 1) * d], ld)
 
 
 class MMDoubleStreamBlock(nn.Module):
