@@ -2,7 +2,13 @@
 (oracle/vae_ref.py, fp16-emulated contract) and the golden vectors produced by executing the reference's hyvideo/vae code.
 Tolerances: fp16 activations (11-bit mantissa) with fp32 accumulation; kernels and oracle round at the same points,
 so per-op differences are accumulation order (<= 1 fp16 ulp = 2^-10 relative); whole-decoder drift vs the reference's
-fp32 run is bounded at 2e-2 of the output range."""
+fp32 run is bounded at 2e-2 of the output range.
+
+PARITY UNPINNED for one dependency: the mid-block attention (K18) is diffusers' `Attention` class, which the reference imports
+but does not vendor (absent from /root/reference, not installable here).  oracle/vae_ref.mid_attention restates its published
+algorithm (GroupNorm -> q/k/v Linear -> softmax(q k^T / sqrt(C)) v under the reference's own block-causal frame mask,
+unet_causal_3d_blocks.py:579-593 -> to_out + residual); it is pinned only through the decoder-level fixtures below, which were
+produced by executing the reference's decoder WITH a stand-in attention of that definition (tools/make_golden_vae.py says so)."""
 import math
 
 import pytest
