@@ -52,7 +52,7 @@ SIGNATURES = {
     "hv_groupnorm_finalize_f16": [_p, _l, _l, _i, _i, _f, _p, _p, _p, _p],
     "hv_groupnorm_affine_f16": [_p, _l, _l, _i, _i, _f, _p, _p, _p, _l, _p, _p],
     "hv_groupnorm_apply_f16": [_p, _l, _p, _l, _l, _i, _p, _i, _p],
-    "hv_softmax_rows_f32_f16": [_p, _l, _p, _l, _i, _i, _i, _f, _p],
+    "hv_softmax_rows_f32_f16": [_p, _l, _p, _l, _i, _i, _i, _f, _i, _p],
     "hv_transpose_16b": [_p, _l, _p, _l, _i, _i, _p],
     "hv_conv3d_upsampled_subpixel_f16": [_p, _l, _p, _p, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p, _l, _p],
     "hv_conv3d_causal_strided_f16": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -236,27 +236,60 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
     }
 }
 
-// ---- row softmax: P[r][c] = softmax_c(scale * S[r][c]) for c < cols, 0 for cols <= c < cols_pad; fp32 in, fp16 out
+// ---- row softmax: P[r][c] = softmax_c(scale * S[r][c]) for c < valid(r), 0 for valid(r) <= c < cols_pad; fp32 in, fp16 out.
+// valid(r) = cols, or with causal_block > 0 the frame-causal mask of prepare_causal_attention_mask (unet_causal_3d_blocks.py:38-46):
+// min(cols, (r / causal_block + 1) * causal_block) - a query of frame f sees the keys of frames <= f.  VEC = 4: float4 loads and
+// 8-byte stores when strides and extents allow (the VAE's frames are multiples of 4 tokens).
+template <int VEC>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds_, uint16_t* __restrict__ P,
-                                                            int64_t ldp, int rows, int cols, int cols_pad, float scale) {
+                                                            int64_t ldp, int rows, int cols, int cols_pad, float scale,
+                                                            int causal_block) {
     __shared__ float redm[4], reds[4];
     const int r = blockIdx.x;
+    int valid = cols;
+    if (causal_block > 0) valid = min((int)min((int64_t)cols, ((int64_t)(r / causal_block) + 1) * causal_block), cols);
     const float* s = S + (int64_t)r * lds_;
+    uint16_t* p = P + (int64_t)r * ldp;
     float m = -INFINITY;
-    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, s[c]);
+    if constexpr (VEC == 4) {
+        for (int c = threadIdx.x * 4; c < valid; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(s + c);
+            m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        }
+    } else {
+        for (int c = threadIdx.x; c < valid; c += 256) m = fmaxf(m, s[c]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = m;
     __syncthreads();
     m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])) * scale;
     float sum = 0.f;
-    for (int c = threadIdx.x; c < cols; c += 256) sum += __expf(s[c] * scale - m);
+    if constexpr (VEC == 4) {
+        for (int c = threadIdx.x * 4; c < valid; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(s + c);
+            sum += (__expf(v.x * scale - m) + __expf(v.y * scale - m)) + (__expf(v.z * scale - m) + __expf(v.w * scale - m));
+        }
+    } else {
+        for (int c = threadIdx.x; c < valid; c += 256) sum += __expf(s[c] * scale - m);
+    }
     sum = wave_sum(sum);
     if ((threadIdx.x & 63) == 0) reds[threadIdx.x >> 6] = sum;
     __syncthreads();
     const float inv = 1.0f / (reds[0] + reds[1] + reds[2] + reds[3]);
-    uint16_t* p = P + (int64_t)r * ldp;
-    for (int c = threadIdx.x; c < cols_pad; c += 256) p[c] = c < cols ? f2h(__expf(s[c] * scale - m) * inv) : (uint16_t)0;
+    if constexpr (VEC == 4) {
+        for (int c = threadIdx.x * 4; c < cols_pad; c += 1024) {
+            uint2 o = make_uint2(0u, 0u);
+            if (c < valid) {
+                const float4 v = *reinterpret_cast<const float4*>(s + c);
+                o.x = (uint32_t)f2h(__expf(v.x * scale - m) * inv) | ((uint32_t)f2h(__expf(v.y * scale - m) * inv) << 16);
+                o.y = (uint32_t)f2h(__expf(v.z * scale - m) * inv) | ((uint32_t)f2h(__expf(v.w * scale - m) * inv) << 16);
+            }
+            *reinterpret_cast<uint2*>(p + c) = o;
+        }
+    } else {
+        for (int c = threadIdx.x; c < cols_pad; c += 256) p[c] = c < valid ? f2h(__expf(s[c] * scale - m) * inv) : (uint16_t)0;
+    }
 }
 
 // ---- transpose [R][C] (row stride lds) -> [C][R] (row stride ldd), 16-bit elements, 32x32 LDS tiles
@@ -424,9 +457,14 @@ extern "C" int hv_groupnorm_apply_f16(const void* x, int64_t ldx, void* y, int64
 }
 
 extern "C" int hv_softmax_rows_f32_f16(const float* S, int64_t ld_s, void* P, int64_t ld_p, int rows, int cols, int cols_pad,
-                                       float scale, hipStream_t stream) {
-    if (!S || !P || rows <= 0 || cols <= 0 || cols_pad < cols) return HV_ERR_ARG;
-    softmax_rows_kernel<<<dim3(rows), dim3(256), 0, stream>>>(S, ld_s, (uint16_t*)P, ld_p, rows, cols, cols_pad, scale);
+                                       float scale, int causal_block, hipStream_t stream) {
+    if (!S || !P || rows <= 0 || cols <= 0 || cols_pad < cols || causal_block < 0) return HV_ERR_ARG;
+    const bool vec = !(ld_s & 3) && !(ld_p & 3) && !(cols & 3) && !(cols_pad & 3) && !(causal_block & 3) &&
+                     !((uintptr_t)S & 15) && !((uintptr_t)P & 7);
+    if (vec)
+        softmax_rows_kernel<4><<<dim3(rows), dim3(256), 0, stream>>>(S, ld_s, (uint16_t*)P, ld_p, rows, cols, cols_pad, scale, causal_block);
+    else
+        softmax_rows_kernel<1><<<dim3(rows), dim3(256), 0, stream>>>(S, ld_s, (uint16_t*)P, ld_p, rows, cols, cols_pad, scale, causal_block);
     return hv_check_launch();
 }
 

@@ -123,6 +123,9 @@ class AutoencoderKLCausal3D(nn.Module):
         self.tile_latent_min_size = int(sample_size / (2 ** (len(block_out_channels) - 1)))
         self.tile_overlap_factor = 0.25
         self._prep = None
+        # mid-block attention: all frames of a tile in one score matrix while it stays below this size (a 17x32x32 latent tile:
+        # 1.2 GB fp32); larger inputs (untiled decode of a long clip) fall back to one frame of query rows at a time
+        self.mid_attention_batch_bytes = 4 << 30
 
     # ------------------------------------------------------------------ reference surface
     @property
@@ -274,6 +277,17 @@ class AutoencoderKLCausal3D(nn.Module):
         V.transpose_16b(qkv[:L, 2 * C:], vT)
         a = torch.empty(L, C, dtype=F16, device=x.device)
         scale = 1.0 / math.sqrt(C)
+        if L * _r(L, 8) * 4 <= self.mid_attention_batch_bytes:
+            # all frames at once: one score GEMM [L, L] (fp32), one frame-causal softmax, one P.V GEMM - the blocks above the
+            # frame diagonal are computed and masked (0.3 TFLOP per 17x32x32 tile, a fraction of a millisecond) instead of 3 T
+            # small launches whose P.V GEMMs occupy 8 workgroups each
+            S = torch.empty(L, _r(L, 8), dtype=torch.float32, device=x.device)
+            V.gemm_f16(qkv[:L, :C], qkv[:, C:2 * C], None, out=S, out_f32=True, n=_r(L, 8), k=C)
+            Pm = V.softmax_rows(S, L, Lp, scale, causal_block=HW)
+            del S
+            V.gemm_f16(Pm, vT, None, out=a, n=C, k=Lp)
+            wo, bo = P[pre + "to_out.0"]
+            return V.gemm_f16(a, wo, bo, res=x, k=wo.shape[1])
         S = torch.empty(HW, _r(L, 8), dtype=torch.float32, device=x.device)
         Pm = torch.empty(HW, Lp, dtype=F16, device=x.device)
         for f in range(T):

@@ -220,13 +220,13 @@ def groupnorm_apply(x, affine, silu: bool, out=None):
     return out
 
 
-def softmax_rows(s_f32, cols: int, cols_pad: int, scale: float, out=None):
+def softmax_rows(s_f32, cols: int, cols_pad: int, scale: float, out=None, causal_block: int = 0):
+    """P = softmax(scale * S) per row over the first `cols` columns (causal_block = HW: over the keys of frames <= the row's frame)."""
     _chk(s_f32, torch.float32, "S")
     rows = s_f32.shape[0]
     if out is None:
         out = torch.empty(rows, cols_pad, dtype=F16, device=s_f32.device)
-    _lib.call("softmax_rows_f32_f16", s_f32, s_f32.stride(0), out, out.stride(0), rows, cols, cols_pad,
-                                                   scale)
+    _lib.call("softmax_rows_f32_f16", s_f32, s_f32.stride(0), out, out.stride(0), rows, cols, cols_pad, scale, causal_block)
     return out
 
 

@@ -230,11 +230,12 @@ int hv_groupnorm_finalize_f16(const float* partial, int64_t nrow, int64_t M, int
 int hv_groupnorm_apply_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int C, const float* affine,
                            int silu, hipStream_t stream);
 
-/* K18: P = softmax(scale * S) row-wise, fp32 -> fp16, columns [cols, cols_pad) zero-filled (K padding of the P.V GEMM).
- * The frame-causal mask of prepare_causal_attention_mask (unet_causal_3d_blocks.py:38-46) is realised by the caller
- * giving each frame's query rows exactly the key columns of frames <= its own. */
+/* K18: P = softmax(scale * S) row-wise, fp32 -> fp16, columns [valid, cols_pad) zero-filled (K padding of the P.V GEMM).
+ * causal_block = 0: valid = cols for every row.  causal_block = HW > 0: the frame-causal mask of prepare_causal_attention_mask
+ * (unet_causal_3d_blocks.py:38-46) - row r belongs to frame r / HW and sees the keys of frames <= its own: valid =
+ * min(cols, (r / HW + 1) * HW) - so one launch covers all frames of a tile. */
 int hv_softmax_rows_f32_f16(const float* S, int64_t ld_s, void* P, int64_t ld_p, int rows, int cols, int cols_pad,
-                            float scale, hipStream_t stream);
+                            float scale, int causal_block, hipStream_t stream);
 
 /* [R][C] -> [C][R] for 16-bit elements (V^T for the P.V GEMM). */
 int hv_transpose_16b(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C, hipStream_t stream);

@@ -220,6 +220,36 @@ def test_gemm_f16_softmax_transpose(V):
     assert torch.equal(t[:, :300].cpu(), a.to(F16).T) and float(t[:, 300:].abs().max()) == 0
 
 
+def test_frame_causal_softmax(V):
+    """hv_softmax_rows_f32_f16 with causal_block = HW: row r (frame r // HW) normalises over the keys of frames <= its own
+    (prepare_causal_attention_mask, unet_causal_3d_blocks.py:38-46), the rest of the row up to cols_pad is zero.  Vector (HW % 4 == 0)
+    and scalar (odd HW) kernels."""
+    for HW, T in ((8, 5), (7, 3)):
+        L = HW * T
+        Lp = (L + 63) // 64 * 64
+        s = (U((L, (L + 7) // 8 * 8), "cs.s", 3.0)).to(DEV).contiguous()
+        p = V.softmax_rows(s, L, Lp, 0.37, causal_block=HW)
+        ref = torch.zeros(L, Lp)
+        for r in range(L):
+            n = (r // HW + 1) * HW
+            ref[r, :n] = torch.softmax(s[r, :n].cpu() * 0.37, -1)
+        torch.testing.assert_close(p.float().cpu(), ref, rtol=2e-3, atol=1e-4)
+        for r in range(L):
+            assert float(p[r, (r // HW + 1) * HW:].abs().max() if (r // HW + 1) * HW < Lp else 0) == 0
+
+
+def test_mid_attention_batched_equals_per_frame():
+    """The mid-block attention over all frames in one score matrix (default for a tile) against the per-frame loop it replaces
+    (kept for inputs whose score matrix would not fit): same GEMMs and masks, only the softmax's summation order differs."""
+    boc = (32, 64, 128, 128)
+    vae, _ = _vae(boc, 256, 64)
+    z = syn.hashed_uniform((1, 16, 4, 8, 8), "ma.z", 0) * 1.7
+    y_b = vae.decode(z.to(DEV), return_dict=False)[0].float().cpu()
+    vae.mid_attention_batch_bytes = 0
+    y_f = vae.decode(z.to(DEV), return_dict=False)[0].float().cpu()
+    assert rel(y_b, y_f) < 2e-3, rel(y_b, y_f)
+
+
 def test_blend_copy_postprocess(V, golden):
     g = golden("vae_blend")
     a, b = g["a"][0].to(DEV).to(F16), g["b"][0].to(DEV).to(F16)      # [C,T,H,W]
