@@ -187,6 +187,49 @@ def test_conv3d_production_shapes_sampled_voxels(name, cin, cout, T, Hh, W, up):
     torch.testing.assert_close(out[lin].float().cpu(), ref, rtol=2 ** -9, atol=4e-3)
 
 
+@pytest.mark.parametrize("name,c,sT,sH,sW,up_t,mode", [
+    ("512ch_t_hw", 512, 17, 64, 64, True, "fast"),          # up_blocks.1 upsampler -> 33 x 128 x 128 (8 parity classes, 8 taps)
+    ("256ch_hw", 256, 65, 128, 128, False, "fast"),         # up_blocks.2 upsampler -> 65 x 256 x 256 (4 classes, 12 taps): the largest
+    ("512ch_t_hw_exact", 512, 9, 32, 32, True, "exact"),    # residue taps: 15 per class
+])
+def test_subpixel_upsampler_production_shapes_sampled_voxels(name, c, sT, sH, sW, up_t, mode):
+    """hv_conv3d_upsampled_subpixel_f16 at the shipped upsampler shapes against the DIRECT definition (nearest upsample, then the
+    27-tap causal conv, fp64 on sampled output voxels incl. every border): the class -> voxel scatter, the per-class tap offsets and
+    the 32-bit offset arithmetic at 4.26 M output rows.  `fast` carries one extra fp16 rounding per summed weight (<= 2 ulp)."""
+    from hunyuanvideo_efficiency_amd import vae_ops as V
+    T, Hh, W = (2 * sT - 1 if up_t else sT), 2 * sH, 2 * sW
+    x = _u((sT * sH * sW, c), "sp.x." + name, 1.0, F16)
+    w5 = _u((c, c, 3, 3, 3), "sp.w." + name, 1 / math.sqrt(27 * c), F16)
+    b = _u((c,), "sp.b." + name, 0.1, F16)
+    w_sub, table, ntap = V.subpixel_weights(w5, up_t, mode)
+    out, st = V.conv3d_upsampled_subpixel(x, w_sub, table, ntap, b, sT, sH, sW, c, c, up_t, gn_stats=True)
+    torch.cuda.synchronize()
+    assert out.shape == (T * Hh * W, c)
+    vox = _sample_voxels(T, Hh, W, 600, "sp.v." + name)
+    wt = w5.permute(0, 2, 3, 4, 1).reshape(c, 27, c).contiguous()
+    ref = _conv_ref_voxels(x, sT, sH, sW, wt, b, vox, T, Hh, W, up_t, True)
+    lin = ((vox[:, 0] * Hh + vox[:, 1]) * W + vox[:, 2]).to(DEV)
+    torch.testing.assert_close(out[lin].float().cpu(), ref, rtol=2 ** -9, atol=4e-3 if mode == "exact" else 6e-3)
+    # the epilogue's GroupNorm statistics of this tensor == a separate pass over it
+    gw, gb = (1 + _u((c,), "sp.gw", 0.1, F16).float()).to(F16), _u((c,), "sp.gb", 0.1, F16)
+    torch.testing.assert_close(V.groupnorm_affine_from_stats(st, gw, gb), V.groupnorm_affine(out, gw, gb), rtol=5e-5, atol=5e-6)
+
+
+def test_conv_epilogue_statistics_largest_activation():
+    """GroupNorm statistics from the epilogue of the 128 -> 128 conv at 65 x 256 x 256 (66,560 partial rows, two-level fp64 fold)
+    against the separate statistics pass over the stored tensor."""
+    from hunyuanvideo_efficiency_amd import vae_ops as V
+    T, Hh, W, c = 65, 256, 256, 128
+    x = _u((T * Hh * W, c), "es.x", 1.0, F16)
+    wt = _u((c, 27, c), "es.w", 1 / math.sqrt(27 * c), F16)
+    b = _u((c,), "es.b", 0.1, F16)
+    res = _u((T * Hh * W, c), "es.r", 1.0, F16)
+    out, st = V.conv3d_causal(x, wt, b, T, Hh, W, c, c, res=res, gn_stats=True)
+    assert st.rows == 4 * ((T * Hh * W + 255) // 256)
+    gw, gb = (1 + _u((c,), "es.gw", 0.1, F16).float()).to(F16), _u((c,), "es.gb", 0.1, F16)
+    torch.testing.assert_close(V.groupnorm_affine_from_stats(st, gw, gb), V.groupnorm_affine(out, gw, gb), rtol=5e-5, atol=5e-6)
+
+
 def test_groupnorm_production_shape():
     """GroupNorm(32) + SiLU over the largest activation (65x256x256 x 128 channels): statistics over 17 M elements per group."""
     from hunyuanvideo_efficiency_amd import vae_ops as V
