@@ -925,7 +925,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
 // =====================================================================================================================
 // v5 = v4 with the per-tile barrier moved two MFMA gaps before the end of the iteration (see gap 30 in body_main): the next
 // tile's LDS-DMA issue and its first K fragment reads ride under the last two MFMAs.
-__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5(AttnArgs a) {
+// NW = waves per workgroup: 8 (256 query rows) or 4 (128 query rows, two workgroups per CU: the same two waves per SIMD, but each
+// workgroup has its own barrier, so the two waves of a SIMD no longer reach every per-tile barrier together)
+// (the body is a device function template and the two kernels plain __global__ wrappers: as a __global__ TEMPLATE in this file the
+// host stubs of attn_fwd_kernel_v5<4/8> stayed undefined symbols - hipcc 7.2 - although gemm8_kernel's instantiate fine)
+template <int NW>
+__device__ __forceinline__ void attn_v5_body(AttnArgs a) {
+    constexpr int KEYS_W = KVT / NW, NP = KEYS_W / 4;       // keys a wave stages per tile, 1-KiB DMA pieces (4 keys) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | V0 | V1], 16 KiB each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -937,7 +943,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5(AttnArgs a) {
         a.v += (int64_t)kv0 * a.sv;
         a.n_kv = min(a.n_kv - kv0, a.split_keys);
     }
-    const int q0 = qt * QTILE + wave * QROWS_WAVE;
+    const int q0 = qt * (QROWS_WAVE * NW) + wave * QROWS_WAVE;
     constexpr int KOFF = 0, VOFF = 2 * KV_TILE_BYTES;
 
     bf16x8 qf[8];
@@ -955,27 +961,27 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5(AttnArgs a) {
         }
     }
 
-    // ---- DMA addressing: wave w owns keys [8w, 8w+8) of a tile; piece i (0,1): key = 8w + 4i + (lane>>4), LDS chunk pos = lane&15.
+    // ---- DMA addressing: wave w owns keys [KEYS_W*w, KEYS_W*(w+1)) of a tile; piece i: key = KEYS_W*w + 4i + (lane>>4), LDS chunk pos = lane&15.
     // LDS-DMA by buffer_load ... lds: the descriptor (4 SGPRs, rebuilt per tile by scalar arithmetic) starts at the tile and covers
     // exactly its valid rows, the per-lane byte offset never changes.  Keys past n_kv in a ragged last tile fall outside the
     // descriptor: the hardware range check returns zeros for them - no clamped copies of the offsets (4 VGPRs), no selects; those
     // keys are masked to -inf after the S MFMAs as before.
     const char* kbase = reinterpret_cast<const char*>(a.k + head * D);
     const char* vbase = reinterpret_cast<const char*>(a.v + head * D);
-    uint32_t koff[2], voff[2];
+    uint32_t koff[NP], voff[NP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int key = 8 * wave + (lane >> 4) + 4 * i, dcp = lane & 15;
+    for (int i = 0; i < NP; ++i) {
+        const int key = KEYS_W * wave + (lane >> 4) + 4 * i, dcp = lane & 15;
         koff[i] = (uint32_t)(key * (int)a.sk * 2 + ((dcp ^ (key & 15)) << 4));
         voff[i] = (uint32_t)(key * (int)a.sv * 2 + ((dcp ^ ((key & 3) << 2)) << 4));
     }
-    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 2048;   // 8 keys x 256 B; scalar: the DMA destination goes through M0
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * (KEYS_W * 256);   // KEYS_W keys x 256 B; scalar: the DMA destination goes through M0
     const int64_t k_tile_bytes = (int64_t)KVT * a.sk * 2, v_tile_bytes = (int64_t)KVT * a.sv * 2;
-    auto dma_tile = [&](const char* base, int64_t tile_bytes, int row_bytes, const uint32_t (&off)[2], int tile, int lds_base) {
+    auto dma_tile = [&](const char* base, int64_t tile_bytes, int row_bytes, const uint32_t (&off)[NP], int tile, int lds_base) {
         const int rows = min(a.n_kv - tile * KVT, KVT);
         auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + tile * tile_bytes), 0, rows * row_bytes, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NP; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(smem + lds_base + wave_lds + i * 1024), 16, off[i], 0, 0, 0);
     };
     auto dma_k = [&](int tile, int buf) { dma_tile(kbase, k_tile_bytes, (int)a.sk * 2, koff, tile, KOFF + buf * KV_TILE_BYTES); };
@@ -1272,6 +1278,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5(AttnArgs a) {
     }
 }
 
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5(AttnArgs a) { attn_v5_body<8>(a); }
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel_v5w4(AttnArgs a) { attn_v5_body<4>(a); }
+
 
 // merge the KV-split partials: O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m),  m = max_s m_s  (log2 domain)
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
@@ -1308,7 +1317,7 @@ inline int attn_ver() {
     const char* e2 = std::getenv("HV_ATTN_V2");
     if (e2 && e2[0] == '1') return 2;
     const char* e = std::getenv("HV_ATTN_VER");
-    return e && e[0] >= '2' && e[0] <= '5' ? e[0] - '0' : 5;
+    return e && e[0] >= '2' && e[0] <= '6' ? e[0] - '0' : 5;
 }
 
 int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
@@ -1319,6 +1328,12 @@ int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
     } else if (ver == 5) {
         if (hv_set_max_lds(g_attn5_lds_once, (const void*)attn_fwd_kernel_v5, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
         attn_fwd_kernel_v5<<<grid, dim3(512), ATT_LDS, stream>>>(a);
+    } else if (ver == 6) {      // the same kernel as 4-wave workgroups of 128 query rows, two per CU
+        static HvPerDeviceOnce once6;
+        if (hv_set_max_lds(once6, (const void*)attn_fwd_kernel_v5w4, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
+        AttnArgs a4 = a;
+        a4.n_qtiles = (a.n_q + 127) / 128;
+        attn_fwd_kernel_v5w4<<<dim3((unsigned)(a4.n_qtiles * a.n_heads), grid.y), dim3(256), ATT_LDS, stream>>>(a4);
     } else if (ver == 4) {
         if (hv_set_max_lds(g_attn4_lds_once, (const void*)attn_fwd_kernel_v4, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
         attn_fwd_kernel_v4<<<grid, dim3(512), ATT_LDS, stream>>>(a);
