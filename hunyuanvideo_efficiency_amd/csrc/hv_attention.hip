@@ -929,7 +929,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
 // workgroup has its own barrier, so the two waves of a SIMD no longer reach every per-tile barrier together)
 // (the body is a device function template and the two kernels plain __global__ wrappers: as a __global__ TEMPLATE in this file the
 // host stubs of attn_fwd_kernel_v5<4/8> stayed undefined symbols - hipcc 7.2 - although gemm8_kernel's instantiate fine)
-template <int NW>
+template <int NW, bool DOT2 = false>
 __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
     constexpr int KEYS_W = KVT / NW, NP = KEYS_W / 4;       // keys a wave stages per tile, 1-KiB DMA pieces (4 keys) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | V0 | V1], 16 KiB each
@@ -1125,7 +1125,14 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
         // row sum: one pinned v_add_f32 per value, issued ONE GAP AFTER its v_exp_f32 (a pure `ls += p` chain is emitted as 32
         // dependent adds after the last gap with all 32 values held live; pinned in the exp's own gap an asm add could sit in the
         // trans->VALU forwarding slot, which the compiler only pads for instructions it can see)
-        auto acc = [&](float p) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls) : "v"(p)); };
+        auto acc = [&](float p) {
+            if constexpr (!DOT2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(ls) : "v"(p));
+        };
+        // DOT2: the row sum is taken from the PACKED bf16 pairs the P.V MFMAs consume - one v_dot2_f32_bf16 with (1, 1) per pair
+        // instead of two v_add_f32 (l = sum of the rounded weights that multiply V), pinned one gap after the pack
+        auto acc2 = [&](uint32_t w) {
+            if constexpr (DOT2) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(ls) : "v"(w), "v"(0x3F803F80u));
+        };
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 32; ++g) {
@@ -1135,6 +1142,8 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
                 if (g >= 1) {
                     acc(P0[g - 1]);
                     if (!((g - 1) & 1)) acc(P1[(g - 1) >> 1]);
+                    if (!(g & 1)) acc2(w0[(g - 1) >> 3][((g - 1) & 7) >> 1]);            // packed at gap g-1 (odd)
+                    if (((g - 1) & 3) == 2) acc2(w1[0][(((g - 1) >> 1) & 7) >> 1]);      // e = (g-1)/2 odd: packed at gap g-1
                 }
                 Sn[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 4], qf[g & 7], (g & 7) == 0 ? negm : Sn[g >> 3], 0, 0, 0);
                 P0[g] = __builtin_amdgcn_exp2f(Sc[0][g]);
@@ -1159,6 +1168,8 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
                 else if (t + 2 < ntiles) fr[(g + 2) % 4] = knext(g - 30);      // gaps 30, 31 -> K(t+2) fragments 0, 1 (slots 0, 1)
                 if (j == 0) acc(P0[15]);
                 if (j >= 1 && j <= 8) acc(P1[7 + j]);
+                if (j == 0) acc2(w0[1][3]);                                               // packed at gap 15
+                if (j >= 2 && j <= 8 && !(j & 1)) acc2(w1[1][((8 + j - 1) & 7) >> 1]);    // e = 8 + (j-1) odd: packed at gap g-1
                 const int s_ = (j >> 2) & 1, db = j & 3;
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, j < 8 ? w0[s_] : w1[s_]);
                 oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 4], pf, oT[db], 0, 0, 0);
@@ -1280,6 +1291,7 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
 
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5(AttnArgs a) { attn_v5_body<8>(a); }
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_v5w4(AttnArgs a) { attn_v5_body<4>(a); }
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5d(AttnArgs a) { attn_v5_body<8, true>(a); }
 
 
 // merge the KV-split partials: O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m),  m = max_s m_s  (log2 domain)
@@ -1317,7 +1329,7 @@ inline int attn_ver() {
     const char* e2 = std::getenv("HV_ATTN_V2");
     if (e2 && e2[0] == '1') return 2;
     const char* e = std::getenv("HV_ATTN_VER");
-    return e && e[0] >= '2' && e[0] <= '6' ? e[0] - '0' : 5;
+    return e && e[0] >= '2' && e[0] <= '7' ? e[0] - '0' : 5;
 }
 
 int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
@@ -1328,6 +1340,10 @@ int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
     } else if (ver == 5) {
         if (hv_set_max_lds(g_attn5_lds_once, (const void*)attn_fwd_kernel_v5, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
         attn_fwd_kernel_v5<<<grid, dim3(512), ATT_LDS, stream>>>(a);
+    } else if (ver == 7) {      // row sums by v_dot2_f32_bf16 on the packed pairs
+        static HvPerDeviceOnce once7;
+        if (hv_set_max_lds(once7, (const void*)attn_fwd_kernel_v5d, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
+        attn_fwd_kernel_v5d<<<grid, dim3(512), ATT_LDS, stream>>>(a);
     } else if (ver == 6) {      // the same kernel as 4-wave workgroups of 128 query rows, two per CU
         static HvPerDeviceOnce once6;
         if (hv_set_max_lds(once6, (const void*)attn_fwd_kernel_v5w4, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
