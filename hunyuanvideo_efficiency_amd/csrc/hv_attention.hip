@@ -1159,7 +1159,10 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
                     // the tile's one barrier sits HERE, two MFMAs before the end: every LDS read of this iteration has been issued
                     // (the last V fragments at gap 29), the DMAs started a whole iteration ago have long landed, so the next
                     // iteration's DMAs and its first two K fragment reads go under the last two MFMAs instead of in front of an
-                    // idle matrix pipe after the barrier (8 waves x ~150 cycles of LDS latency + ~30 scalar instructions per tile)
+                    // idle matrix pipe after the barrier (8 waves x ~150 cycles of LDS latency + ~30 scalar instructions per tile).
+                    // vmcnt(0): __syncthreads() alone compiles to lgkmcnt(0) + s_barrier here - the compiler does not count LDS-DMA
+                    // as something a workgroup fence waits for; the DMAs this retires were issued a whole iteration ago (free)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     if (t + 3 < ntiles) dma_k(t + 3, (t + 1) & 1);
                     if (t + 2 < ntiles) dma_v(t + 2, t & 1);
@@ -1207,6 +1210,7 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
     dma_k(0, 0);
     dma_v(0, 0);
     if (ntiles > 1) dma_k(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K(0) / V(0) must have landed: the barrier alone does not wait for LDS-DMA
     __syncthreads();
     {
         f32x16 zero;
@@ -1289,6 +1293,376 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
     }
 }
 
+// =====================================================================================================================
+// v8: the v5 program on v_mfma_f32_16x16x32_bf16.  Why: the chip holds its clock down under this kernel (~1.7 GHz), and the clock it
+// holds depends on the MFMA shape - a 16x16x32 loop delivers ~1.12-1.15x the FLOP/s of a 32x32x16 loop at equal cycles per FLOP
+// (MI355X_MICROARCH.md "DVFS give-back" item 7; the GEMMs of this library already use that shape).  Same algorithm, tile sizes, LDS
+// images, DMA and register budget; what changes is which lane owns what:
+//   S^T block (16 keys x 16 queries) = K frag (lane: key l16, k chunk g) x Q'^T frag (lane: query l16, k chunk g), l16 = lane & 15,
+//   g = lane >> 4: a lane holds keys 4g + r (r = 0..3) of key block kb for query (qb, l16) - 8 blocks (4 kb x 2 qb) per wave and KV tile,
+//   4 k-steps each; a K fragment feeds the two query blocks.  Row max / row sum: lane-local over 16 values per query block, then the
+//   four lanes l16 + 16g by v_permlane16_swap + v_permlane32_swap (no LDS).
+//   O^T block (16 dims x 16 queries) += V^T frag x P^T frag: the B operand's 8 k-slots of lane (query l16, g) are its own
+//   exponentials of key blocks 2kp and 2kp + 1 (keys 16(2kp) + 4g + r, 16(2kp+1) + 4g + r) - straight from the accumulators through
+//   cvt_pk, no lane exchange; the A operand takes the same keys of dim l16 by two ds_read_b64_tr_b16 (one per key block).  8 dim blocks
+//   x 2 query blocks x 2 key-block pairs = 32 MFMAs, a V fragment feeds the two query blocks.
+// 64 MFMA gaps of 16 cycles per tile: gaps 0-31 S'(t+1) || 24 of the tile's 32 exponentials, gaps 32-47 O += V.P (pair 0) || the other 8,
+// gaps 48-63 O += V.P (pair 1) || row max of S'(t+1); K/V fragments through a 4-slot ring two fragment steps (4 gaps) ahead; barrier
+// at gap 60, next tile's DMA and first two K fragments under the last four MFMAs.
+// compile-time loop: the body sees its index as a constant expression (a `#pragma unroll` loop of 64 large iterations was left
+// rolled - an inner loop with runtime indices into P[], pw[], Sc[]: 1,387 scratch instructions, 50 TFLOP/s)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// v8's schedule of the 32 exponentials of a tile over its 64 MFMA gaps: three of every four gaps of the S phase (0..23), every
+// second gap of the first P.V phase (24..31); -1 = none
+__host__ __device__ constexpr int exp_of_gap(int gp) {
+    return gp < 0 ? -1 : gp < 32 ? ((gp & 3) != 3 ? gp - (gp >> 2) : -1) : (gp < 48 && !(gp & 1)) ? 24 + ((gp - 32) >> 1) : -1;
+}
+
+__device__ __forceinline__ float quad_rows_max(float v) {       // over the lanes l16 + 16 g, g = 0..3
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float quad_rows_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+#ifndef HV_DBG_NOP
+#define HV_DBG_NOP ""
+#endif
+#ifndef HV_DBG_NOP2
+#define HV_DBG_NOP2 ""
+#endif
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v8(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | V0 | V1], 16 KiB each
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int head = blockIdx.x / a.n_qtiles;
+    const int qt = blockIdx.x % a.n_qtiles;
+    if (a.n_splits > 1) {   // this workgroup's key range
+        const int kv0 = blockIdx.y * a.split_keys;
+        a.k += (int64_t)kv0 * a.sk;
+        a.v += (int64_t)kv0 * a.sv;
+        a.n_kv = min(a.n_kv - kv0, a.split_keys);
+    }
+    const int q0 = qt * QTILE + wave * QROWS_WAVE;
+    constexpr int KOFF = 0, VOFF = 2 * KV_TILE_BYTES;
+
+    bf16x8 qf[2][4];      // Q' = bf16(Q * scale * log2 e) fragments: [query block][k-step]
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = min(q0 + qb * 16 + l16, a.n_q - 1);
+        const bf16_t* qp = a.q + (int64_t)qrow * a.sq + head * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qp + ks * 32);
+            u32x4 sc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[j] = pack_bf2(bf2f_lo(raw[j]) * a.scale_log2e, bf2f_hi(raw[j]) * a.scale_log2e);
+            qf[qb][ks] = __builtin_bit_cast(bf16x8, sc);
+        }
+    }
+
+    // ---- DMA: as v5 (wave w stages keys [8w, 8w+8) of a tile, two 1-KiB pieces per tensor, descriptor sized to the valid rows)
+    const char* kbase = reinterpret_cast<const char*>(a.k + head * D);
+    const char* vbase = reinterpret_cast<const char*>(a.v + head * D);
+    uint32_t koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = 8 * wave + (lane >> 4) + 4 * i, dcp = lane & 15;
+        koff[i] = (uint32_t)(key * (int)a.sk * 2 + ((dcp ^ (key & 15)) << 4));
+        voff[i] = (uint32_t)(key * (int)a.sv * 2 + ((dcp ^ ((key & 3) << 2)) << 4));
+    }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 2048;
+    const int64_t k_tile_bytes = (int64_t)KVT * a.sk * 2, v_tile_bytes = (int64_t)KVT * a.sv * 2;
+    auto dma_tile = [&](const char* base, int64_t tile_bytes, int row_bytes, const uint32_t (&off)[2], int tile, int lds_base) {
+        const int rows = min(a.n_kv - tile * KVT, KVT);
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + tile * tile_bytes), 0, rows * row_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(smem + lds_base + wave_lds + i * 1024), 16, off[i], 0, 0, 0);
+    };
+    auto dma_k = [&](int tile, int buf) { dma_tile(kbase, k_tile_bytes, (int)a.sk * 2, koff, tile, KOFF + buf * KV_TILE_BYTES); };
+    auto dma_v = [&](int tile, int buf) { dma_tile(vbase, v_tile_bytes, (int)a.sv * 2, voff, tile, VOFF + buf * KV_TILE_BYTES); };
+
+    // ---- fragment read addresses.  K: key kb*16 + l16, 16-B chunk ks*4 + g at LDS position chunk ^ (key & 15);
+    // V^T (tr read, a 16-lane row = 4 keys x 16 dims): key kb*16 + 4g + vq, dims db*16 + 4vp .. +3, chunk position ^ ((key & 3) << 2)
+    const int kread = l16 * 256 + ((g ^ l16) << 4);                                   // + kb * 4096, ^ (ks << 6)
+    const int vq = l16 >> 2, vp = l16 & 3;
+    const int vread = (4 * g + vq) * 256 + (((vp >> 1) ^ (vq << 2)) << 4) + (vp & 1) * 8;   // + kb * 4096, ^ (db << 5)
+
+    f32x4 oT[2][8];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int db = 0; db < 8; ++db) oT[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    f32x4 negm[2];       // -m_run of the lane's query in each block: the C operand of every S chain (deferred max, see v3)
+    bf16x8 fr[4];        // K/V fragment ring: fragment step s (two gaps) uses slot s % 4, loaded two steps ahead
+    constexpr float THR = 8.0f;
+    const int ntiles = (a.n_kv + KVT - 1) / KVT;
+
+    auto vfrag = [&](const char* vb_, int kp, int db) {
+        const char* p0 = vb_ + kp * 8192 + (vread ^ (db << 5));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 4096));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto qk_plain = [&](f32x4 (&S)[2][4], int buf, const f32x4 (&c0)[2]) {
+        const char* kb_ = smem + KOFF + buf * KV_TILE_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_ + kb * 4096 + (kread ^ (ks << 6)));
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    S[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], ks == 0 ? c0[qb] : S[qb][kb], 0, 0, 0);
+            }
+    };
+    // tail mask (last tile) + row max of a score tile (relative to m_run) per query block
+    auto tile_max = [&](f32x4 (&Sc)[2][4], int t, bool last, float (&mx)[2]) {
+        if (last && (a.n_kv & (KVT - 1))) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * KVT + kb * 16 + 4 * g + r >= a.n_kv) Sc[qb][kb][r] = -INFINITY;
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float m = Sc[qb][0][0];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, Sc[qb][kb][r]);
+            mx[qb] = quad_rows_max(m);
+        }
+    };
+    // rare: some row exceeds the running max by more than THR -> move every row's max, rescale sums, this tile's scores, the C operand
+    auto raise_max = [&](f32x4 (&Sc)[2][4], const float (&mx)[2]) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float d = fmaxf(mx[qb], 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            l_run[qb] *= alpha;
+            m_run[qb] += d;
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oT[qb][db][r] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Sc[qb][kb][r] -= d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) negm[qb][r] = -m_run[qb];
+        }
+        asm volatile("" : "+v"(negm[0]), "+v"(negm[1]));
+    };
+    // the tile's exponentials in the order the P.V phases need them: v = 0..15 key-block pair 0, 16..31 pair 1;
+    // within a pair: (qb, kb & 1, r) = (v >> 3 & 1, v >> 2 & 1, v & 3)
+    // steady-state iteration: consumes Sc = S'(t) and its row maxima, produces Sn = S'(t+1) and its maxima
+    auto body_main = [&](f32x4 (&Sc)[2][4], f32x4 (&Sn)[2][4], int t, const float (&mx_c)[2], float (&mx_n)[2], auto next_last_c) {
+        constexpr bool NEXT_LAST = decltype(next_last_c)::value;
+        // on entry: fr[0], fr[1] hold K(t+1) fragments 0 and 1; the DMAs of K(t+2) and V(t+1) are in flight
+        if (__any(mx_c[0] > THR || mx_c[1] > THR)) raise_max(Sc, mx_c);
+        const char* kb_ = smem + KOFF + ((t + 1) & 1) * KV_TILE_BYTES;
+        const char* vb_ = smem + VOFF + (t & 1) * KV_TILE_BYTES;
+        const char* kn_ = smem + KOFF + (t & 1) * KV_TILE_BYTES;      // K(t+2) will land where K(t) was
+        auto kload = [&](const char* base, int f) {                     // f = kb * 4 + ks
+            return *reinterpret_cast<const bf16x8*>(base + (f >> 2) * 4096 + (kread ^ ((f & 3) << 6)));
+        };
+        u32x4 pw[2][2];                 // packed P: [query block][key-block pair], the B operand of the P.V MFMAs
+        float P[32];
+        float ls0 = 0.f, ls1 = 0.f, mx0 = -INFINITY, mx1 = -INFINITY;
+        auto acc = [&](int v) {          // row sum: one pinned v_add_f32 per value, one gap after its v_exp_f32 (see v4)
+            if ((v >> 3) & 1) asm volatile(HV_DBG_NOP "v_add_f32 %0, %0, %1" : "+v"(ls1) : "v"(P[v]));
+            else asm volatile(HV_DBG_NOP "v_add_f32 %0, %0, %1" : "+v"(ls0) : "v"(P[v]));
+        };
+        auto expv = [&](int v) {
+            const int kp = v >> 4, qb = (v >> 3) & 1, kbl = (v >> 2) & 1, r = v & 3;
+            P[v] = __builtin_amdgcn_exp2f(Sc[qb][2 * kp + kbl][r]);
+            if (r & 1) pw[qb][kp][kbl * 2 + (r >> 1)] = pack_bf2(P[v - 1], P[v]);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 64>([&](auto gpc) {
+            constexpr int gp = decltype(gpc)::value;
+            constexpr int s_ = gp >> 1;                     // fragment step of this gap
+            if constexpr (!(gp & 1)) {                      // even gap: fetch the fragment of step s_ + 2
+                constexpr int n = s_ + 2;
+                if constexpr (gp == 60) {
+                    // the tile's one barrier: every LDS read of this iteration has been issued (the last V fragment at gap 58); the
+                    // next iteration's DMAs and its first two K fragments ride under the last four MFMAs
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // see v5: __syncthreads() does not wait for LDS-DMA
+                    __syncthreads();
+                    if (t + 3 < ntiles) dma_k(t + 3, (t + 1) & 1);
+                    if (t + 2 < ntiles) dma_v(t + 2, t & 1);
+                }
+                if constexpr (n < 16) fr[n % 4] = kload(kb_, n);
+                else if constexpr (n < 32) fr[n % 4] = vfrag(vb_, (n - 16) >> 3, (n - 16) & 7);
+                else if (t + 2 < ntiles) fr[n % 4] = kload(kn_, n - 32);
+            }
+            if constexpr (gp < 32) {
+                // ---- S'(t+1): K fragment s_ = kb*4 + ks feeds query blocks 0 (even gap) and 1 (odd gap)
+                constexpr int kb = s_ >> 2, ks = s_ & 3, qb = gp & 1;
+                constexpr int ve = gp - (gp >> 2);              // exponential of this gap (gaps with (gp & 3) == 3 carry none): 0..23
+                Sn[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[s_ % 4], qf[qb][ks], ks == 0 ? negm[qb] : Sn[qb][kb], 0, 0, 0);
+                // row-sum add of the exponential taken TWO gaps ago, behind this gap's MFMA: the compiler pads the trans -> VALU
+                // forwarding hazard only for instructions it can see, and one 16-cycle MFMA between a v_exp_f32 and an inline-asm
+                // v_add_f32 of its result is not enough (run-to-run different sums: measured) - two MFMAs and the gap's fillers are
+                if constexpr (exp_of_gap(gp - 2) >= 0) acc(exp_of_gap(gp - 2));
+                if constexpr ((gp & 3) != 3) expv(ve);
+            } else {
+                constexpr int j = gp - 32;
+                constexpr int kp = j >> 4, db = (j >> 1) & 7, qb = j & 1;
+                oT[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[s_ % 4], __builtin_bit_cast(bf16x8, pw[qb][kp]), oT[qb][db], 0, 0, 0);
+                if constexpr (exp_of_gap(gp - 2) >= 0) acc(exp_of_gap(gp - 2));
+                if constexpr (j < 16 && !(j & 1)) expv(24 + (j >> 1));
+                if constexpr (j >= 16 && !NEXT_LAST) {
+                    // row max of S'(t+1): one v_max3 per gap, two values of one query block (its chains retired >= 16 gaps ago)
+                    constexpr int i = j - 16, qm = i & 1, pr = i >> 1;       // pr = 0..7 -> values 2pr, 2pr+1 of the 16 per block
+                    constexpr int kbm = pr >> 1, rm = (pr & 1) * 2;
+                    if constexpr (qm) asm volatile(HV_DBG_NOP2 "v_max3_f32 %0, %0, %1, %2" : "+v"(mx1) : "v"(Sn[1][kbm][rm]), "v"(Sn[1][kbm][rm + 1]));
+                    else asm volatile(HV_DBG_NOP2 "v_max3_f32 %0, %0, %1, %2" : "+v"(mx0) : "v"(Sn[0][kbm][rm]), "v"(Sn[0][kbm][rm + 1]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (NEXT_LAST) tile_max(Sn, t + 1, t + 2 == ntiles, mx_n);
+        else {
+            mx_n[0] = quad_rows_max(mx0);
+            mx_n[1] = quad_rows_max(mx1);
+        }
+        l_run[0] += ls0;
+        l_run[1] += ls1;
+    };
+    auto body_last = [&](f32x4 (&Sc)[2][4], int t, const float (&mx_c)[2]) {
+        if (__any(mx_c[0] > THR || mx_c[1] > THR)) raise_max(Sc, mx_c);
+        const char* vb_ = smem + VOFF + (t & 1) * KV_TILE_BYTES;
+        u32x4 pw[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float ls = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(Sc[qb][kb][r]);
+                    const float p1 = __builtin_amdgcn_exp2f(Sc[qb][kb][r + 1]);
+                    ls += p0;
+                    ls += p1;
+                    pw[qb][kb >> 1][(kb & 1) * 2 + (r >> 1)] = pack_bf2(p0, p1);
+                }
+            l_run[qb] += ls;
+        }
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                const bf16x8 vf = vfrag(vb_, kp, db);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    oT[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pw[qb][kp]), oT[qb][db], 0, 0, 0);
+            }
+    };
+
+    f32x4 sA[2][4], sB[2][4];
+    dma_k(0, 0);
+    dma_v(0, 0);
+    if (ntiles > 1) dma_k(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K(0) / V(0) must have landed: the barrier alone does not wait for LDS-DMA
+    __syncthreads();
+    {
+        const f32x4 zero[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        qk_plain(sA, 0, zero);
+    }
+    // tile 0 fixes the initial max exactly: m_run = rowmax(S(0)), S'(0) = S(0) - m_run (the only explicit subtraction)
+    tile_max(sA, 0, ntiles == 1, m_run);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sA[qb][kb][r] -= m_run[qb];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) negm[qb][r] = -m_run[qb];
+    }
+    asm volatile("" : "+v"(negm[0]), "+v"(negm[1]));
+    __syncthreads();   // every wave finished reading K[0] before tile 2 is DMA'd over it
+    if (ntiles > 2) dma_k(2, 0);
+    if (ntiles > 1) {
+        dma_v(1, 1);
+        const char* k1_ = smem + KOFF + KV_TILE_BYTES;
+        fr[0] = *reinterpret_cast<const bf16x8*>(k1_ + kread);
+        fr[1] = *reinterpret_cast<const bf16x8*>(k1_ + (kread ^ (1 << 6)));
+    }
+    int t = 0;
+    float mxA[2] = {0.f, 0.f}, mxB[2] = {0.f, 0.f};
+    for (; t + 3 < ntiles; t += 2) {
+        body_main(sA, sB, t, mxA, mxB, std::false_type{});
+        body_main(sB, sA, t + 1, mxB, mxA, std::false_type{});
+    }
+    for (; t + 1 < ntiles; ++t) {
+        body_main(sA, sB, t, mxA, mxB, std::true_type{});
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) sA[qb][kb] = sB[qb][kb];
+        mxA[0] = mxB[0];
+        mxA[1] = mxB[1];
+    }
+    body_last(sA, t, mxA);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int db = 0; db < 8; ++db) asm volatile("" : : "v"(oT[qb][db]));
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = quad_rows_sum(l_run[qb]);
+        const int qrow = q0 + qb * 16 + l16;
+        if (a.n_splits > 1 || a.partial) {   // partial result: O^T unnormalised (fp32) + (m, l); merged by attn_combine_kernel
+            if (qrow < a.n_q) {
+                const int64_t rowi = ((int64_t)blockIdx.y * a.n_q + qrow) * a.n_heads + head;
+                float* po = a.part_o + rowi * D + 4 * g;
+#pragma unroll
+                for (int db = 0; db < 8; ++db)
+                    *reinterpret_cast<float4*>(po + db * 16) = make_float4(oT[qb][db][0], oT[qb][db][1], oT[qb][db][2], oT[qb][db][3]);
+                if (g == 0) {
+                    a.part_ml[rowi * 2] = m_run[qb];
+                    a.part_ml[rowi * 2 + 1] = l_tot;
+                }
+            }
+            continue;
+        }
+        const float inv = 1.0f / l_tot;
+        if (qrow < a.n_q) {
+            bf16_t* op = a.o + (int64_t)qrow * a.so + head * D + 4 * g;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                u32x2 w;
+                w[0] = pack_bf2(oT[qb][db][0] * inv, oT[qb][db][1] * inv);
+                w[1] = pack_bf2(oT[qb][db][2] * inv, oT[qb][db][3] * inv);
+                *reinterpret_cast<u32x2*>(op + db * 16) = w;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5(AttnArgs a) { attn_v5_body<8>(a); }
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_v5w4(AttnArgs a) { attn_v5_body<4>(a); }
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5d(AttnArgs a) { attn_v5_body<8, true>(a); }
@@ -1329,7 +1703,7 @@ inline int attn_ver() {
     const char* e2 = std::getenv("HV_ATTN_V2");
     if (e2 && e2[0] == '1') return 2;
     const char* e = std::getenv("HV_ATTN_VER");
-    return e && e[0] >= '2' && e[0] <= '7' ? e[0] - '0' : 5;
+    return e && e[0] >= '2' && e[0] <= '8' ? e[0] - '0' : 5;
 }
 
 int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
@@ -1340,6 +1714,10 @@ int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
     } else if (ver == 5) {
         if (hv_set_max_lds(g_attn5_lds_once, (const void*)attn_fwd_kernel_v5, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
         attn_fwd_kernel_v5<<<grid, dim3(512), ATT_LDS, stream>>>(a);
+    } else if (ver == 8) {      // the v5 program on v_mfma_f32_16x16x32_bf16
+        static HvPerDeviceOnce once8;
+        if (hv_set_max_lds(once8, (const void*)attn_fwd_kernel_v8, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
+        attn_fwd_kernel_v8<<<grid, dim3(512), ATT_LDS, stream>>>(a);
     } else if (ver == 7) {      // row sums by v_dot2_f32_bf16 on the packed pairs
         static HvPerDeviceOnce once7;
         if (hv_set_max_lds(once7, (const void*)attn_fwd_kernel_v5d, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
