@@ -935,8 +935,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
 // workgroup has its own barrier, so the two waves of a SIMD no longer reach every per-tile barrier together)
 // (the body is a device function template and the two kernels plain __global__ wrappers: as a __global__ TEMPLATE in this file the
 // host stubs of attn_fwd_kernel_v5<4/8> stayed undefined symbols - hipcc 7.2 - although gemm8_kernel's instantiate fine)
-template <int NW, bool DOT2 = false>
+// PD = how many MFMA gaps ahead of its MFMA a K/V fragment is read from LDS (ring of RING = 2*PD register slots), see body_main
+template <int NW, bool DOT2 = false, int PD = 2>
 __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
+    constexpr int RING = 2 * PD;
     constexpr int KEYS_W = KVT / NW, NP = KEYS_W / 4;       // keys a wave stages per tile, 1-KiB DMA pieces (4 keys) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | V0 | V1], 16 KiB each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1018,7 +1020,7 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
     // pipe ready for exp2 - no scale/subtract pass on the VALU at all.
     float m_run = 0.f, l_run = 0.f;
     f32x16 negm;
-    bf16x8 fr[4];      // 4-slot K/V fragment ring (gap g uses slot g % 4, loaded two gaps ahead; 32 gaps per tile keep the slots aligned)
+    bf16x8 fr[RING];   // K/V fragment ring (gap g uses slot g % RING, loaded PD gaps ahead; 32 gaps per tile keep the slots aligned)
     constexpr float THR = 8.0f;
     const int ntiles = (a.n_kv + KVT - 1) / KVT;
 
@@ -1143,15 +1145,21 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
 #pragma unroll
         for (int g = 0; g < 32; ++g) {
             if (g < 16) {
-                if (g + 2 < 16) fr[(g + 2) % 4] = kload(g + 2);
-                else fr[(g + 2) % 4] = vload(g - 14);
+#ifndef HV_DBG_NOLDS
+#ifndef HV_DBG_NOK
+                if (g + PD < 16) fr[(g + PD) % RING] = kload(g + PD);
+#endif
+#ifndef HV_DBG_NOV
+                if (g + PD >= 16) fr[(g + PD) % RING] = vload(g + PD - 16);
+#endif
+#endif
                 if (g >= 1) {
                     acc(P0[g - 1]);
                     if (!((g - 1) & 1)) acc(P1[(g - 1) >> 1]);
                     if (!(g & 1)) acc2(w0[(g - 1) >> 3][((g - 1) & 7) >> 1]);            // packed at gap g-1 (odd)
                     if (((g - 1) & 3) == 2) acc2(w1[0][(((g - 1) >> 1) & 7) >> 1]);      // e = (g-1)/2 odd: packed at gap g-1
                 }
-                Sn[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 4], qf[g & 7], (g & 7) == 0 ? negm : Sn[g >> 3], 0, 0, 0);
+                Sn[g >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % RING], qf[g & 7], (g & 7) == 0 ? negm : Sn[g >> 3], 0, 0, 0);
                 P0[g] = HV_DBG_EXP(Sc[0][g]);
                 if (g & 1) w0[g >> 3][(g & 7) >> 1] = pack_bf2(P0[g - 1], P0[g]);
                 if (!(g & 1)) {
@@ -1161,27 +1169,35 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
                 }
             } else {
                 const int j = g - 16;
-                if (g == 30) {
+                if (g == 32 - PD) {
                     // the tile's one barrier sits HERE, two MFMAs before the end: every LDS read of this iteration has been issued
                     // (the last V fragments at gap 29), the DMAs started a whole iteration ago have long landed, so the next
                     // iteration's DMAs and its first two K fragment reads go under the last two MFMAs instead of in front of an
                     // idle matrix pipe after the barrier (8 waves x ~150 cycles of LDS latency + ~30 scalar instructions per tile).
                     // vmcnt(0): __syncthreads() alone compiles to lgkmcnt(0) + s_barrier here - the compiler does not count LDS-DMA
                     // as something a workgroup fence waits for; the DMAs this retires were issued a whole iteration ago (free)
+#ifndef HV_DBG_NOBAR
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     if (t + 3 < ntiles) dma_k(t + 3, (t + 1) & 1);
                     if (t + 2 < ntiles) dma_v(t + 2, t & 1);
+#endif
                 }
-                if (j + 2 < 16) fr[(g + 2) % 4] = vload(j + 2);
-                else if (t + 2 < ntiles) fr[(g + 2) % 4] = knext(g - 30);      // gaps 30, 31 -> K(t+2) fragments 0, 1 (slots 0, 1)
+#ifndef HV_DBG_NOLDS
+#ifndef HV_DBG_NOV
+                if (j + PD < 16) fr[(g + PD) % RING] = vload(j + PD);
+#endif
+#ifndef HV_DBG_NOK
+                if (j + PD >= 16 && t + 2 < ntiles) fr[(g + PD) % RING] = knext(g + PD - 32);      // the last PD gaps -> K(t+2) fragments 0 .. PD-1
+#endif
+#endif
                 if (j == 0) acc(P0[15]);
                 if (j >= 1 && j <= 8) acc(P1[7 + j]);
                 if (j == 0) acc2(w0[1][3]);                                               // packed at gap 15
                 if (j >= 2 && j <= 8 && !(j & 1)) acc2(w1[1][((8 + j - 1) & 7) >> 1]);    // e = 8 + (j-1) odd: packed at gap g-1
                 const int s_ = (j >> 2) & 1, db = j & 3;
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, j < 8 ? w0[s_] : w1[s_]);
-                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % 4], pf, oT[db], 0, 0, 0);
+                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % RING], pf, oT[db], 0, 0, 0);
                 if (j < 8) {
                     const int e = 8 + j;
                     P1[e] = HV_DBG_EXP(Sc[1][e]);
@@ -1239,8 +1255,8 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
     if (ntiles > 1) {
         dma_v(1, 1);
         const char* k1_ = smem + KOFF + KV_TILE_BYTES;
-        fr[0] = *reinterpret_cast<const bf16x8*>(k1_ + kread[0]);
-        fr[1] = *reinterpret_cast<const bf16x8*>(k1_ + (kread[0] ^ (1 << 5)));
+#pragma unroll
+        for (int i = 0; i < PD; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(k1_ + (kread[0] ^ (i << 5)));
     }
     int t = 0;
     float mxA = 0.f, mxB = 0.f;
@@ -1672,6 +1688,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v8(AttnArgs a) {
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5(AttnArgs a) { attn_v5_body<8>(a); }
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_v5w4(AttnArgs a) { attn_v5_body<4>(a); }
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5d(AttnArgs a) { attn_v5_body<8, true>(a); }
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v9(AttnArgs a) { attn_v5_body<8, false, 4>(a); }
 
 
 // merge the KV-split partials: O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m),  m = max_s m_s  (log2 domain)
@@ -1709,7 +1726,7 @@ inline int attn_ver() {
     const char* e2 = std::getenv("HV_ATTN_V2");
     if (e2 && e2[0] == '1') return 2;
     const char* e = std::getenv("HV_ATTN_VER");
-    return e && e[0] >= '2' && e[0] <= '8' ? e[0] - '0' : 5;
+    return e && e[0] >= '2' && e[0] <= '9' ? e[0] - '0' : 5;
 }
 
 int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
@@ -1720,6 +1737,10 @@ int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
     } else if (ver == 5) {
         if (hv_set_max_lds(g_attn5_lds_once, (const void*)attn_fwd_kernel_v5, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
         attn_fwd_kernel_v5<<<grid, dim3(512), ATT_LDS, stream>>>(a);
+    } else if (ver == 9) {      // v5 with the K/V fragments read four MFMA gaps ahead (8-slot ring)
+        static HvPerDeviceOnce once9;
+        if (hv_set_max_lds(once9, (const void*)attn_fwd_kernel_v9, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
+        attn_fwd_kernel_v9<<<grid, dim3(512), ATT_LDS, stream>>>(a);
     } else if (ver == 8) {      // the v5 program on v_mfma_f32_16x16x32_bf16
         static HvPerDeviceOnce once8;
         if (hv_set_max_lds(once8, (const void*)attn_fwd_kernel_v8, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;

@@ -45,7 +45,7 @@ def _check(ops, q, k, v, H, atol=8e-3):
     ref = _ref(q, k, v)
     got = _run(ops, q, k, v, H)
     torch.testing.assert_close(got.float().cpu(), ref, rtol=2 ** -7, atol=atol)
-    for ver in ("2", "3", "4", "6", "7", "8"):     # the previous kernels on the same data: equal to bf16 rounding of the output
+    for ver in ("2", "3", "4", "6", "7", "8", "9"):     # the previous kernels on the same data: equal to bf16 rounding of the output
         os.environ["HV_ATTN_VER"] = ver
         try:
             old = _run(ops, q, k, v, H)
