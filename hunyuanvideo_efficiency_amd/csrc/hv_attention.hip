@@ -936,8 +936,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
 // (the body is a device function template and the two kernels plain __global__ wrappers: as a __global__ TEMPLATE in this file the
 // host stubs of attn_fwd_kernel_v5<4/8> stayed undefined symbols - hipcc 7.2 - although gemm8_kernel's instantiate fine)
 // PD = how many MFMA gaps ahead of its MFMA a K/V fragment is read from LDS (ring of RING = 2*PD register slots), see body_main
-template <int NW, bool DOT2 = false, int PD = 2>
+// ALT (NW = 8): the two waves of a SIMD (w and w + 4) take turns issuing the tile's DMA - in the unrolled pair of iterations the waves
+// of group t & 1 issue all eight pieces of their key rows (both 32-key halves), the other group none - so that in every tile one
+// wave of each SIMD keeps feeding the matrix pipe while its sibling is busy with descriptor arithmetic and DMA issue
+template <int NW, bool DOT2 = false, int PD = 2, bool ALT = false>
 __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
+    static_assert(!ALT || NW == 8, "ALT pairs waves w and w + 4");
     constexpr int RING = 2 * PD;
     constexpr int KEYS_W = KVT / NW, NP = KEYS_W / 4;       // keys a wave stages per tile, 1-KiB DMA pieces (4 keys) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | V0 | V1], 16 KiB each
@@ -979,21 +983,40 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
     uint32_t koff[NP], voff[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int key = KEYS_W * wave + (lane >> 4) + 4 * i, dcp = lane & 15;
+        const int key = (ALT ? 8 * (wave & 3) : KEYS_W * wave) + (lane >> 4) + 4 * i, dcp = lane & 15;     // ALT: position inside a 32-key half
         koff[i] = (uint32_t)(key * (int)a.sk * 2 + ((dcp ^ (key & 15)) << 4));
         voff[i] = (uint32_t)(key * (int)a.sv * 2 + ((dcp ^ ((key & 3) << 2)) << 4));
     }
-    const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * (KEYS_W * 256);   // KEYS_W keys x 256 B; scalar: the DMA destination goes through M0
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int dgrp = wave_u >> 2;                                            // ALT: which of a SIMD's two waves; its own half of the keys
+    const int wave_lds = (ALT ? (wave_u & 3) : wave_u) * (KEYS_W * 256);     // KEYS_W keys x 256 B; scalar: the DMA destination goes through M0
     const int64_t k_tile_bytes = (int64_t)KVT * a.sk * 2, v_tile_bytes = (int64_t)KVT * a.sv * 2;
-    auto dma_tile = [&](const char* base, int64_t tile_bytes, int row_bytes, const uint32_t (&off)[NP], int tile, int lds_base) {
+    // half: ALT only - which 32-key half of the tile (scalar offset of the buffer load; the descriptor still covers the whole tile, so
+    // the range check on voffset + soffset zero-fills keys past n_kv); -1 = both halves (the double-duty turn)
+    auto dma_tile = [&](const char* base, int64_t tile_bytes, int row_bytes, const uint32_t (&off)[NP], int tile, int lds_base, int half) {
         const int rows = min(a.n_kv - tile * KVT, KVT);
         auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + tile * tile_bytes), 0, rows * row_bytes, 0x00020000);
+        if constexpr (ALT) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(smem + lds_base + wave_lds + i * 1024), 16, off[i], 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                if (half >= 0 && half != h) continue;
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(smem + lds_base + h * 8192 + wave_lds + i * 1024), 16, off[i],
+                                                             h * 32 * row_bytes, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(smem + lds_base + wave_lds + i * 1024), 16, off[i], 0, 0, 0);
+        }
     };
-    auto dma_k = [&](int tile, int buf) { dma_tile(kbase, k_tile_bytes, (int)a.sk * 2, koff, tile, KOFF + buf * KV_TILE_BYTES); };
-    auto dma_v = [&](int tile, int buf) { dma_tile(vbase, v_tile_bytes, (int)a.sv * 2, voff, tile, VOFF + buf * KV_TILE_BYTES); };
+    auto dma_k = [&](int tile, int buf, int half = -2) {
+        dma_tile(kbase, k_tile_bytes, (int)a.sk * 2, koff, tile, KOFF + buf * KV_TILE_BYTES, half == -2 ? dgrp : half);
+    };
+    auto dma_v = [&](int tile, int buf, int half = -2) {
+        dma_tile(vbase, v_tile_bytes, (int)a.sv * 2, voff, tile, VOFF + buf * KV_TILE_BYTES, half == -2 ? dgrp : half);
+    };
 
     int kread[2];
 #pragma unroll
@@ -1111,8 +1134,9 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
     //   gaps 16-23  O += V.P block 0 (V fragments 2 ahead)    | exp/pack of P block 1, elements 8..15
     //   gaps 24-31  O += V.P block 1                          | row max of S'(t+1), 4 values per gap
     // NEXT_LAST: tile t+1 may be the (possibly ragged) last one - its masked row max is taken after the gaps instead.
-    auto body_main = [&](f32x16 (&Sc)[2], f32x16 (&Sn)[2], int t, float mx_c, float& mx_n, auto next_last_c) {
+    auto body_main = [&](f32x16 (&Sc)[2], f32x16 (&Sn)[2], int t, float mx_c, float& mx_n, auto next_last_c, auto par_c) {
         constexpr bool NEXT_LAST = decltype(next_last_c)::value;
+        constexpr int PAR = decltype(par_c)::value;      // ALT: the wave group whose turn it is to issue this iteration's DMA (-1: everyone its own half)
         // on entry: fr[0], fr[1] hold K(t+1) fragments 0 and 1; the DMAs of K(t+2) and V(t+1) are in flight
         if (__any(mx_c > THR)) raise_max(Sc, mx_c);
         const char* kb_ = smem + KOFF + ((t + 1) & 1) * KV_TILE_BYTES;
@@ -1179,8 +1203,13 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
 #ifndef HV_DBG_NOBAR
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (t + 3 < ntiles) dma_k(t + 3, (t + 1) & 1);
-                    if (t + 2 < ntiles) dma_v(t + 2, t & 1);
+                    if (!ALT || PAR < 0) {
+                        if (t + 3 < ntiles) dma_k(t + 3, (t + 1) & 1);
+                        if (t + 2 < ntiles) dma_v(t + 2, t & 1);
+                    } else if (dgrp == PAR) {
+                        if (t + 3 < ntiles) dma_k(t + 3, (t + 1) & 1, -1);
+                        if (t + 2 < ntiles) dma_v(t + 2, t & 1, -1);
+                    }
 #endif
                 }
 #ifndef HV_DBG_NOLDS
@@ -1263,13 +1292,13 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
     // inside the loop neither call may PRODUCE the last tile (t+1 and t+2 <= ntiles-2): no mask code there, the row max rides
     // under the P.V MFMAs; the 1-3 tiles left over take the masked variant for the call that produces the last tile
     for (; t + 3 < ntiles; t += 2) {
-        body_main(sA, sB, t, mxA, mxB, std::false_type{});
-        body_main(sB, sA, t + 1, mxB, mxA, std::false_type{});
+        body_main(sA, sB, t, mxA, mxB, std::false_type{}, std::integral_constant<int, 0>{});      // t even
+        body_main(sB, sA, t + 1, mxB, mxA, std::false_type{}, std::integral_constant<int, 1>{});
     }
     // the 0-2 iterations left before the final tile: ONE more instance of the body (row max after the gaps, tail mask when the
     // tile it produces is the last), scores handed back through a register copy instead of a second unrolled name swap
     for (; t + 1 < ntiles; ++t) {
-        body_main(sA, sB, t, mxA, mxB, std::true_type{});
+        body_main(sA, sB, t, mxA, mxB, std::true_type{}, std::integral_constant<int, -1>{});
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) sA[kb] = sB[kb];
         mxA = mxB;
@@ -1689,6 +1718,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5(AttnArgs a) { attn_
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_v5w4(AttnArgs a) { attn_v5_body<4>(a); }
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5d(AttnArgs a) { attn_v5_body<8, true>(a); }
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v9(AttnArgs a) { attn_v5_body<8, false, 4>(a); }
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5a(AttnArgs a) { attn_v5_body<8, false, 2, true>(a); }
 
 
 // merge the KV-split partials: O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m),  m = max_s m_s  (log2 domain)
@@ -1726,6 +1756,7 @@ inline int attn_ver() {
     const char* e2 = std::getenv("HV_ATTN_V2");
     if (e2 && e2[0] == '1') return 2;
     const char* e = std::getenv("HV_ATTN_VER");
+    if (e && e[0] == '1' && e[1] == '0') return 10;
     return e && e[0] >= '2' && e[0] <= '9' ? e[0] - '0' : 5;
 }
 
@@ -1737,6 +1768,10 @@ int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
     } else if (ver == 5) {
         if (hv_set_max_lds(g_attn5_lds_once, (const void*)attn_fwd_kernel_v5, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
         attn_fwd_kernel_v5<<<grid, dim3(512), ATT_LDS, stream>>>(a);
+    } else if (ver == 10) {     // v5 with the DMA issue taken in turns by the two waves of a SIMD
+        static HvPerDeviceOnce once10;
+        if (hv_set_max_lds(once10, (const void*)attn_fwd_kernel_v5a, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
+        attn_fwd_kernel_v5a<<<grid, dim3(512), ATT_LDS, stream>>>(a);
     } else if (ver == 9) {      // v5 with the K/V fragments read four MFMA gaps ahead (8-slot ring)
         static HvPerDeviceOnce once9;
         if (hv_set_max_lds(once9, (const void*)attn_fwd_kernel_v9, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
