@@ -57,6 +57,11 @@ def test_torch_custom_ops_registered_for_every_entry_point():
     assert int(hv.abi_version()) == _lib.ABI_VERSION
     assert _lib.host("attn_suggest_splits", 118811, 118811, 3) == 2        # Ulysses-8 shape: shallow grid -> KV split
     assert _lib.host("attn_suggest_splits", 118811, 118811, 24) == 1
+    # rows of the GroupNorm-statistics buffer a conv epilogue fills: one per 64 output rows, whole 256-row tiles; the sub-pixel
+    # upsampler forms its tiles per output parity class (8 classes when T is upsampled: 4 with sT frames, 4 with sT - 1)
+    assert _lib.host("gn_partial_rows", 65 * 256 * 256) == 66560 and _lib.host("gn_partial_rows", 90) == 4
+    assert _lib.host("subpixel_gn_partial_rows", 17, 64, 64, 1) == 4 * (4 * 272 + 4 * 256)
+    assert _lib.host("subpixel_gn_partial_rows", 1, 4, 4, 1) == 4 * 4 and _lib.host("subpixel_gn_partial_rows", 65, 128, 128, 0) == 4 * 4 * 4160
     with pytest.raises(_lib.HVKernelError):
         _lib.call("euler_step_f32", torch.zeros(4), torch.zeros(4, dtype=torch.bfloat16), 0.1, 4)
 
