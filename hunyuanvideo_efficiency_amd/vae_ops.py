@@ -192,7 +192,7 @@ def groupnorm_affine(x, weight, bias, groups: int = 32, eps: float = 1e-6):
     """per-channel (scale, shift) fp32 [C, 2] of GroupNorm(groups) over all rows of x [M, C]."""
     _chk(x, F16, "x"), _chk(weight, F16, "weight"), _chk(bias, F16, "bias")
     m, c = x.shape
-    key = (str(x.device), c)
+    key = (str(x.device), c, torch.cuda.current_stream(x.device).cuda_stream)     # per stream: tiles are decoded on several at once
     ws = _gn_ws.get(key)
     if ws is None:
         ws = torch.empty(1024 * c * 2, dtype=torch.float32, device=x.device)

@@ -238,6 +238,19 @@ def test_frame_causal_softmax(V):
             assert float(p[r, (r // HW + 1) * HW:].abs().max() if (r // HW + 1) * HW < Lp else 0) == 0
 
 
+def test_tiles_on_two_streams_bit_identical():
+    """decode_streams = 2 (independent tiles of a tiled decode on two HIP streams, greedy by size): same kernels on the same data."""
+    boc = (32, 64, 128, 128)
+    vae, _ = _vae(boc, 64, 16)
+    vae.enable_tiling()
+    z = syn.hashed_uniform((1, 16, 6, 14, 12), "st.z", 0) * 1.7
+    y1 = vae.decode(z.to(DEV), return_dict=False)[0]
+    vae.decode_streams = 2
+    y2 = vae.decode(z.to(DEV), return_dict=False)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+
+
 def test_mid_attention_batched_equals_per_frame():
     """The mid-block attention over all frames in one score matrix (default for a tile) against the per-frame loop it replaces
     (kept for inputs whose score matrix would not fit): same GEMMs and masks, only the softmax's summation order differs."""
