@@ -126,10 +126,9 @@ class AutoencoderKLCausal3D(nn.Module):
         # mid-block attention: all frames of a tile in one score matrix while it stays below this size (a 17x32x32 latent tile:
         # 1.2 GB fp32); larger inputs (untiled decode of a long clip) fall back to one frame of query rows at a time
         self.mid_attention_batch_bytes = 4 << 30
-        # tiled decode: independent tiles can be decoded on this many HIP streams at once (1 = strictly one after the other, the
-        # default: two streams measured 3.46 s against 3.40 s - the LDS-bound conv kernels hold one workgroup per CU, so a second
-        # tile's kernels find almost no room beside them)
-        self.decode_streams = 1
+        # tiled decode: independent tiles are decoded on this many HIP streams at once (1 = strictly one after the other).  Same box:
+        # 3.50 / 3.48 s on one stream, 3.20 / 3.20 s on two, 3.69 s on three (tools/bench_vae_streams.py; bit-identical outputs)
+        self.decode_streams = 2
         self._streams = None
 
     # ------------------------------------------------------------------ reference surface

@@ -239,11 +239,13 @@ def test_frame_causal_softmax(V):
 
 
 def test_tiles_on_two_streams_bit_identical():
-    """decode_streams = 2 (independent tiles of a tiled decode on two HIP streams, greedy by size): same kernels on the same data."""
+    """decode_streams = 2 (the default: independent tiles of a tiled decode on two HIP streams, greedy by size) against one stream:
+    same kernels on the same data."""
     boc = (32, 64, 128, 128)
     vae, _ = _vae(boc, 64, 16)
     vae.enable_tiling()
     z = syn.hashed_uniform((1, 16, 6, 14, 12), "st.z", 0) * 1.7
+    vae.decode_streams = 1
     y1 = vae.decode(z.to(DEV), return_dict=False)[0]
     vae.decode_streams = 2
     y2 = vae.decode(z.to(DEV), return_dict=False)[0]
