@@ -939,9 +939,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v4(AttnArgs a) {
 // ALT (NW = 8): the two waves of a SIMD (w and w + 4) take turns issuing the tile's DMA - in the unrolled pair of iterations the waves
 // of group t & 1 issue all eight pieces of their key rows (both 32-key halves), the other group none - so that in every tile one
 // wave of each SIMD keeps feeding the matrix pipe while its sibling is busy with descriptor arithmetic and DMA issue
-template <int NW, bool DOT2 = false, int PD = 2, bool ALT = false>
+// S2: four-deep K and V tile rings (128 KiB) and ONE barrier per TWO tiles: the odd iteration of the unrolled pair synchronises and
+// issues the DMAs of two tiles of each tensor (K(t+4), K(t+5), V(t+3), V(t+4): their slots were released by this or the previous
+// barrier), the even iteration has no barrier and no DMA at all; see body_main for the read / landing argument
+template <int NW, bool DOT2 = false, int PD = 2, bool ALT = false, bool S2 = false>
 __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
     static_assert(!ALT || NW == 8, "ALT pairs waves w and w + 4");
+    static_assert(!(ALT && S2), "one experiment at a time");
+    constexpr int NBUF = S2 ? 4 : 2;
     constexpr int RING = 2 * PD;
     constexpr int KEYS_W = KVT / NW, NP = KEYS_W / 4;       // keys a wave stages per tile, 1-KiB DMA pieces (4 keys) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | V0 | V1], 16 KiB each
@@ -956,7 +961,7 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
         a.n_kv = min(a.n_kv - kv0, a.split_keys);
     }
     const int q0 = qt * (QROWS_WAVE * NW) + wave * QROWS_WAVE;
-    constexpr int KOFF = 0, VOFF = 2 * KV_TILE_BYTES;
+    constexpr int KOFF = 0, VOFF = NBUF * KV_TILE_BYTES;
 
     bf16x8 qf[8];
     {
@@ -1139,8 +1144,8 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
         constexpr int PAR = decltype(par_c)::value;      // ALT: the wave group whose turn it is to issue this iteration's DMA (-1: everyone its own half)
         // on entry: fr[0], fr[1] hold K(t+1) fragments 0 and 1; the DMAs of K(t+2) and V(t+1) are in flight
         if (__any(mx_c > THR)) raise_max(Sc, mx_c);
-        const char* kb_ = smem + KOFF + ((t + 1) & 1) * KV_TILE_BYTES;
-        const char* vb_ = smem + VOFF + (t & 1) * KV_TILE_BYTES;
+        const char* kb_ = smem + KOFF + ((t + 1) & (NBUF - 1)) * KV_TILE_BYTES;
+        const char* vb_ = smem + VOFF + (t & (NBUF - 1)) * KV_TILE_BYTES;
         auto kload = [&](int i) { return *reinterpret_cast<const bf16x8*>(kb_ + (kread[i >> 3] ^ ((i & 7) << 5))); };
         auto vload = [&](int j) {      // j = (kb*2 + s)*4 + db
             const int koff_ = ((j >> 3) * 32 + 16 * ((j >> 2) & 1)) * 256;
@@ -1149,7 +1154,7 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * 256));
             return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         };
-        const char* kn_ = smem + KOFF + (t & 1) * KV_TILE_BYTES;      // K(t+2) will land where K(t) was
+        const char* kn_ = smem + KOFF + ((t + 2) & (NBUF - 1)) * KV_TILE_BYTES;      // K(t+2) (two buffers: where K(t) was)
         auto knext = [&](int i) { return *reinterpret_cast<const bf16x8*>(kn_ + (kread[i >> 3] ^ ((i & 7) << 5))); };
         u32x4 w0[2], w1[2];
         float P0[16], P1[16];          // this tile's exponentials (compile-time indices: registers, each live for about one gap)
@@ -1201,6 +1206,21 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
                     // vmcnt(0): __syncthreads() alone compiles to lgkmcnt(0) + s_barrier here - the compiler does not count LDS-DMA
                     // as something a workgroup fence waits for; the DMAs this retires were issued a whole iteration ago (free)
 #ifndef HV_DBG_NOBAR
+                    if constexpr (S2) {
+                        // S2, t odd (compile-time in the unrolled pair, run-time in the tail iterations): K(t+4) over K(t) (last read
+                        // in iteration t-1), K(t+5) over K(t+1) (read in this iteration's S phase), V(t+3) over V(t-1), V(t+4) over
+                        // V(t) (read up to gap 29) - all released by this barrier; what the next two iterations read (K(t+2), K(t+3),
+                        // V(t+1), V(t+2), and K(t+3)/K(t+4) fragments at their ends) was issued at the previous barrier or this one
+                        // and is retired by this barrier's / the next one's vmcnt(0)
+                        if (PAR == 1 || (PAR < 0 && (t & 1))) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __syncthreads();
+                            if (t + 4 < ntiles) dma_k(t + 4, (t + 4) & 3);
+                            if (t + 5 < ntiles) dma_k(t + 5, (t + 5) & 3);
+                            if (t + 3 < ntiles) dma_v(t + 3, (t + 3) & 3);
+                            if (t + 4 < ntiles) dma_v(t + 4, (t + 4) & 3);
+                        }
+                    } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     if (!ALT || PAR < 0) {
@@ -1209,6 +1229,7 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
                     } else if (dgrp == PAR) {
                         if (t + 3 < ntiles) dma_k(t + 3, (t + 1) & 1, -1);
                         if (t + 2 < ntiles) dma_v(t + 2, t & 1, -1);
+                    }
                     }
 #endif
                 }
@@ -1251,9 +1272,9 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
         bf16x8 p0[2], p1[2];
         float ls = 0.f;
         exp_block(Sc[0], p0, ls);
-        pv_block(p0, 0, t & 1);
+        pv_block(p0, 0, t & (NBUF - 1));
         exp_block(Sc[1], p1, ls);
-        pv_block(p1, 1, t & 1);
+        pv_block(p1, 1, t & (NBUF - 1));
         l_run += ls;
     };
 
@@ -1280,9 +1301,20 @@ __device__ __forceinline__ void attn_v5_body(AttnArgs a) {
     asm volatile("" : "+v"(negm));
     __syncthreads();   // every wave finished reading K[0] before tile 2 is DMA'd over it
     // entry state of the first iteration: DMAs of K(2) and V(1) in flight, K(1) fragments 0 and 1 in fr[0], fr[1]
-    if (ntiles > 2) dma_k(2, 0);
+    if constexpr (S2) {
+        // everything the first pair of iterations reads before the first in-loop barrier (iteration 1, gap 30) must have landed
+        // before the loop starts: K(2..4), V(1..3) now, then one more drain + barrier
+        if (ntiles > 2) dma_k(2, 2);
+        if (ntiles > 3) dma_k(3, 3);
+        if (ntiles > 4) dma_k(4, 0);
+        if (ntiles > 1) dma_v(1, 1);
+        if (ntiles > 2) dma_v(2, 2);
+        if (ntiles > 3) dma_v(3, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else if (ntiles > 2) dma_k(2, 0);
     if (ntiles > 1) {
-        dma_v(1, 1);
+        if constexpr (!S2) dma_v(1, 1);
         const char* k1_ = smem + KOFF + KV_TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < PD; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(k1_ + (kread[0] ^ (i << 5)));
@@ -1719,6 +1751,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_v5w4(AttnArgs a) { att
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5d(AttnArgs a) { attn_v5_body<8, true>(a); }
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v9(AttnArgs a) { attn_v5_body<8, false, 4>(a); }
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5a(AttnArgs a) { attn_v5_body<8, false, 2, true>(a); }
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel_v5s(AttnArgs a) { attn_v5_body<8, false, 2, false, true>(a); }
 
 
 // merge the KV-split partials: O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m),  m = max_s m_s  (log2 domain)
@@ -1757,6 +1790,7 @@ inline int attn_ver() {
     if (e2 && e2[0] == '1') return 2;
     const char* e = std::getenv("HV_ATTN_VER");
     if (e && e[0] == '1' && e[1] == '0') return 10;
+    if (e && e[0] == '1' && e[1] == '1') return 11;
     return e && e[0] >= '2' && e[0] <= '9' ? e[0] - '0' : 5;
 }
 
@@ -1768,6 +1802,10 @@ int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
     } else if (ver == 5) {
         if (hv_set_max_lds(g_attn5_lds_once, (const void*)attn_fwd_kernel_v5, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
         attn_fwd_kernel_v5<<<grid, dim3(512), ATT_LDS, stream>>>(a);
+    } else if (ver == 11) {     // v5 with four-deep K/V rings and one barrier per two tiles
+        static HvPerDeviceOnce once11;
+        if (hv_set_max_lds(once11, (const void*)attn_fwd_kernel_v5s, 8 * KV_TILE_BYTES) != HV_OK) return HV_ERR_LAUNCH;
+        attn_fwd_kernel_v5s<<<grid, dim3(512), 8 * KV_TILE_BYTES, stream>>>(a);
     } else if (ver == 10) {     // v5 with the DMA issue taken in turns by the two waves of a SIMD
         static HvPerDeviceOnce once10;
         if (hv_set_max_lds(once10, (const void*)attn_fwd_kernel_v5a, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;

@@ -45,13 +45,13 @@ def _check(ops, q, k, v, H, atol=8e-3):
     ref = _ref(q, k, v)
     got = _run(ops, q, k, v, H)
     torch.testing.assert_close(got.float().cpu(), ref, rtol=2 ** -7, atol=atol)
-    for ver in ("2", "3", "4", "6", "7", "8", "9", "10"):     # the previous kernels on the same data: equal to bf16 rounding of the output
+    for ver in ("2", "3", "4", "6", "7", "8", "9", "10", "11"):     # the previous kernels on the same data: equal to bf16 rounding of the output
         os.environ["HV_ATTN_VER"] = ver
         try:
             old = _run(ops, q, k, v, H)
         finally:
             os.environ.pop("HV_ATTN_VER", None)
-        if ver in ("6", "9", "10"):      # the same per-wave arithmetic (workgroup shape / prefetch depth / who issues the DMA): identical bits
+        if ver in ("6", "9", "10", "11"):      # the same per-wave arithmetic (workgroup shape / prefetch depth / who issues the DMA): identical bits
             assert torch.equal(got, old)
         else:
             torch.testing.assert_close(got.float().cpu(), old.float().cpu(), rtol=2 ** -6, atol=atol)
