@@ -26,6 +26,7 @@ SIGNATURES = {
     "hv_abi_version": [],
     "hv_ln_modulate_bf16": [_p, _p, _p, _p, _l, _i, _l, _l, _f, _i, _p],
     "hv_qknorm_rope_bf16": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _l, _l, _f, _p],
+    "hv_qknorm_rope_scatter_bf16": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _l, _l, _f, _p, _l, _i, _l, _p],
     "hv_gemm_bf16": [_p, _l, _p, _l, _p, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p, _p, _l, _p],
     "hv_linear_smallm_bf16": [_p, _p, _p, _p, _p, _i, _i, _i, _l, _l, _i, _p],
     "hv_timestep_embedding_bf16": [_p, _p, _i, _i, _f, _p],

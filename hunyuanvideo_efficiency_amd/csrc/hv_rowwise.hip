@@ -252,10 +252,14 @@ extern "C" int hv_quant_rows_fp8(const void* x, int64_t ldx, void* out_q, int64_
 //   rope rows (row < n_rope): out[2i]   = y[2i]*cos[2i]   - y[2i+1]*sin[2i]
 //                             out[2i+1] = y[2i+1]*cos[2i+1] + y[2i]*sin[2i+1]     (fp32, one rounding)
 // 16 lanes own one 128-wide head vector (8 elements = 4 RoPE pairs per lane).
+// dst != nullptr: out of place with a per-head-block scatter - head hv (0 .. 2H-1 in q|k order) of row r goes to
+// dst[(hv / hpb) * dst_bs + r * dst_ld + (hv % hpb) * 128]: the Ulysses send layout [peer][row][heads of that peer], so the pack copy
+// that would follow is this kernel's own store.
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qw,
                                                            const bf16_t* __restrict__ kw, const float* __restrict__ cosT,
                                                            const float* __restrict__ sinT, int64_t n_rows, int64_t n_rope,
-                                                           int H, int64_t ld, int64_t k_off, float eps) {
+                                                           int H, int64_t ld, int64_t k_off, float eps, bf16_t* __restrict__ dst,
+                                                           int64_t dst_ld, int hpb, int64_t dst_bs) {
     const int64_t row = blockIdx.x;
     const int sub = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;  // 16 groups
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16_t* __restrict__ q
         bf16_t* p = qkv + row * ld + (is_k ? k_off : 0) + h * 128 + sub * 8;
         float x[8];
         unpack8(*reinterpret_cast<const u32x4*>(p), x);
+        if (dst) p = dst + (int64_t)(hv / hpb) * dst_bs + row * dst_ld + (hv % hpb) * 128 + sub * 8;
         float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
@@ -308,7 +313,23 @@ extern "C" int hv_qknorm_rope_bf16(void* qkv, const void* q_weight, const void* 
     if (n_rows == 0) return HV_OK;
     qknorm_rope_kernel<<<dim3((unsigned)n_rows), dim3(256), 0, stream>>>((bf16_t*)qkv, (const bf16_t*)q_weight,
                                                                           (const bf16_t*)k_weight, cos_tab, sin_tab, n_rows,
-                                                                          n_rope, n_heads, ld, k_offset, eps);
+                                                                          n_rope, n_heads, ld, k_offset, eps, nullptr, 0, 1, 0);
+    return hv_check_launch();
+}
+
+extern "C" int hv_qknorm_rope_scatter_bf16(const void* qkv, const void* q_weight, const void* k_weight, const float* cos_tab,
+                                           const float* sin_tab, int64_t n_rows, int64_t n_rope, int n_heads, int head_dim,
+                                           int64_t ld, int64_t k_offset, float eps, void* dst, int64_t dst_ld,
+                                           int heads_per_block, int64_t dst_block_stride, hipStream_t stream) {
+    if (!qkv || !dst || !q_weight || !k_weight || head_dim != 128 || n_heads <= 0 || n_rows < 0 || n_rope < 0 || n_rope > n_rows ||
+        (ld & 7) || (k_offset & 7) || (dst_ld & 7) || (dst_block_stride & 7) || heads_per_block <= 0 ||
+        (n_rope > 0 && (!cos_tab || !sin_tab)))
+        return HV_ERR_ARG;
+    if (n_rows == 0) return HV_OK;
+    qknorm_rope_kernel<<<dim3((unsigned)n_rows), dim3(256), 0, stream>>>((bf16_t*)const_cast<void*>(qkv), (const bf16_t*)q_weight,
+                                                                          (const bf16_t*)k_weight, cos_tab, sin_tab, n_rows, n_rope,
+                                                                          n_heads, ld, k_offset, eps, (bf16_t*)dst, dst_ld,
+                                                                          heads_per_block, dst_block_stride);
     return hv_check_launch();
 }
 

@@ -199,6 +199,25 @@ class UlyssesLongContextAttention:
             return None
         return self._bufs[{"q": "qf", "k": "kf", "v": "vf"}[which]][:s_loc]
 
+    def pack_dst(self, which: str) -> Optional[torch.Tensor]:
+        """P > 1: the send buffer of the q / k / v exchange as a [s_loc, P, w] view (row r, peer p at send[p][r][:]) - a producer that
+        can store by head block (ops.qknorm_rope_(..., out=)) writes the packed layout itself and calls send_packed(); None for P = 1."""
+        P, rank, s_loc, n_j, heads, w = self._geo
+        if P == 1:
+            return None
+        send = self._buf("send_" + which, (P * s_loc, w), self._bufs["qf"].device)
+        return send.view(P, s_loc, w).permute(1, 0, 2)
+
+    def send_packed(self, which: str, joint: Optional[torch.Tensor], ld_j: int):
+        """send() for a chunk already stored in pack_dst(which): starts the exchange, places the joint rows."""
+        P, rank, s_loc, n_j, heads, w = self._geo
+        name = {"q": "qf", "k": "kf", "v": "vf"}[which]
+        full = self._bufs[name]
+        send = self._bufs["send_" + which]
+        self._works.append(dist.all_to_all_single(full[:P * s_loc], send, group=self.group, async_op=True))
+        if n_j:
+            self.k.copy3d(joint[:, rank * w:], full[P * s_loc:], 1, n_j, w, 0, ld_j, 0, w)
+
     def send(self, which: str, src: torch.Tensor, ld_src: int, joint: Optional[torch.Tensor], ld_j: int):
         """src: view whose data_ptr is (local image row 0, head 0) of the q / k / v chunk; joint: same for the valid text rows."""
         P, rank, s_loc, n_j, heads, w = self._geo

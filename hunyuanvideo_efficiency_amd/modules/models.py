@@ -107,10 +107,16 @@ def _sp_chunked_qkv(sp, ws: _Workspace, layer, fp8, q_norm_w, k_norm_w, cos, sin
         dst = sp.chunk_dst(which) if hasattr(sp, "chunk_dst") else None
         chunk = dst if dst is not None else ws.qkv[:s_img, c * d:(c + 1) * d]
         _gemm(ws, layer, "xmod", 0, s_img, fp8, wrows=slice(c * d, (c + 1) * d), out=chunk)
+        joint = ws.qkv[s_img:cu1, c * d:(c + 1) * d]
         if norm_w is not None:
-            # the kernel normalises 2 x (H/2) head vectors: with both halves given the same gain that is this chunk's H heads
-            ops.qknorm_rope_(chunk, norm_w, norm_w, cos, sin, n_rope, H // 2, (H // 2) * 128)
-        sp.send(which, chunk, chunk.stride(0), ws.qkv[s_img:cu1, c * d:(c + 1) * d], ld)
+            # the kernel normalises 2 x (H/2) head vectors: with both halves given the same gain that is this chunk's H heads.
+            # P > 1: it stores them straight into the exchange's send layout (head blocks per peer) - the pack copy is its store
+            packed = sp.pack_dst(which) if dst is None and hasattr(sp, "pack_dst") else None
+            ops.qknorm_rope_(chunk, norm_w, norm_w, cos, sin, n_rope, H // 2, (H // 2) * 128, out=packed)
+            if packed is not None:
+                sp.send_packed(which, joint, ld)
+                continue
+        sp.send(which, chunk, chunk.stride(0), joint, ld)
 
 
 class MMDoubleStreamBlock(nn.Module):

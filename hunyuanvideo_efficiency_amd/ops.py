@@ -58,14 +58,23 @@ def ln_modulate(x, shift=None, scale=None, out=None, eps: float = 1e-6, affine: 
     return out
 
 
-def qknorm_rope_(qkv, q_weight, k_weight, cos, sin, n_rope: int, n_heads: int, k_offset: int, eps: float = 1e-6):
-    """in place on qkv rows [n_rows, ld]: RMSNorm(q), RMSNorm(k) per head, RoPE on rows [0, n_rope)."""
+def qknorm_rope_(qkv, q_weight, k_weight, cos, sin, n_rope: int, n_heads: int, k_offset: int, eps: float = 1e-6, out=None):
+    """in place on qkv rows [n_rows, ld]: RMSNorm(q), RMSNorm(k) per head, RoPE on rows [0, n_rope).  With `out` (a 3-D view
+    [n_rows, blocks, heads_per_block*128]): out of place, the 2*n_heads heads scattered by head block (the Ulysses send layout)."""
     _chk(qkv, BF16, "qkv")
     n, _, ld = _rows(qkv, "qkv")
     _chk(q_weight, BF16, "q_weight"), _chk(k_weight, BF16, "k_weight")
     if n_rope > 0:
         _chk(cos, torch.float32, "cos"), _chk(sin, torch.float32, "sin")
         assert cos.is_contiguous() and sin.is_contiguous() and cos.shape[-1] == 128 and cos.shape[0] >= n_rope
+    if out is not None:
+        # out: [n_rows, blocks, heads_per_block*128] view (any block stride): head block b of row r at out[r, b, :]
+        _chk(out, BF16, "out", False)
+        assert out.dim() == 3 and out.shape[0] == n and out.stride(2) == 1 and out.shape[2] % 128 == 0
+        assert out.shape[1] * out.shape[2] == 2 * n_heads * 128, (out.shape, n_heads)
+        _lib.call("qknorm_rope_scatter_bf16", qkv, q_weight, k_weight, cos, sin, n, n_rope, n_heads, 128, ld, k_offset, eps,
+                  out, out.stride(0), out.shape[2] // 128, out.stride(1))
+        return out
     _lib.call("qknorm_rope_bf16", qkv, q_weight, k_weight, cos, sin, n,
                                                n_rope, n_heads, 128, ld, k_offset, eps)
     return qkv

@@ -43,6 +43,15 @@ int hv_qknorm_rope_bf16(void* qkv, const void* q_weight, const void* k_weight, c
                         const float* sin_tab, int64_t n_rows, int64_t n_rope, int n_heads, int head_dim,
                         int64_t ld, int64_t k_offset, float eps, hipStream_t stream);
 
+/* The same, OUT OF PLACE with a scatter by head block (sequence parallelism, hyvideo/modules/attenion.py:169-180: the q / k chunk
+ * that is normalised here is exchanged by an all-to-all over head groups next): head hv of row r (hv = 0 .. 2*n_heads-1 in the
+ * q-then-k order of the source row) is stored at dst[(hv / heads_per_block) * dst_block_stride + r * dst_ld + (hv % heads_per_block)
+ * * 128] - the [peer][row][heads of that peer] send layout - so no pack copy follows.  The source row is not modified. */
+int hv_qknorm_rope_scatter_bf16(const void* qkv, const void* q_weight, const void* k_weight, const float* cos_tab,
+                                const float* sin_tab, int64_t n_rows, int64_t n_rope, int n_heads, int head_dim, int64_t ld,
+                                int64_t k_offset, float eps, void* dst, int64_t dst_ld, int heads_per_block,
+                                int64_t dst_block_stride, hipStream_t stream);
+
 /* K2/K7/K8/K10: nn.Linear on MFMA with fused epilogue.  C = A[M,K] . W[N,K]^T + bias
  *   (models.py:165,186,231,242,339-341,392-393; mlp_layers.py:53-59,117; embed_layers.py:40-59)
  * Columns [0, n_split) go to out0 (row stride ld0) with activation act0, columns [n_split, N) to

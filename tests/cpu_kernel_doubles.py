@@ -33,15 +33,21 @@ def ln_modulate(x, shift=None, scale=None, out=None, eps=1e-6, affine=False):
     return out
 
 
-def qknorm_rope_(qkv, q_weight, k_weight, cos, sin, n_rope, n_heads, k_offset, eps=1e-6):
+def qknorm_rope_(qkv, q_weight, k_weight, cos, sin, n_rope, n_heads, k_offset, eps=1e-6, out=None):
     n = qkv.shape[0]
     d = n_heads * 128
+    res = []
     for off, w in ((0, q_weight), (k_offset, k_weight)):
         x = qkv[:, off:off + d].float().reshape(1, n, n_heads, 128)
         y = R.rms_norm(x, w.float(), E, eps)
         if n_rope:
             y = torch.cat([R.apply_rope(y[:, :n_rope], cos[:n_rope].float(), sin[:n_rope].float(), E), y[:, n_rope:]], 1)
-        qkv[:, off:off + d] = _bf(y.reshape(n, d))
+        if out is None:
+            qkv[:, off:off + d] = _bf(y.reshape(n, d))
+        res.append(_bf(y.reshape(n, d)))
+    if out is not None:      # out of place, scattered by head block: out [n, blocks, heads_per_block*128] (source untouched)
+        out.copy_(torch.cat(res, 1).reshape(n, out.shape[1], out.shape[2]))
+        return out
     return qkv
 
 

@@ -66,6 +66,16 @@ def test_qknorm_rope(ops, n_rows, n_rope, H):
     got = ops.qknorm_rope_(qkv.to(DEV), qw.to(DEV), kw.to(DEV), cos.to(DEV), sin.to(DEV), n_rope, H, H * 128)
     close(got, ref, atol=2e-2)
     assert torch.equal(got[:, 2 * H * 128:].cpu(), qkv[:, 2 * H * 128:])  # v untouched
+    # scatter form (hv_qknorm_rope_scatter_bf16): the same values, out of place, head blocks of hb heads laid out [block][row][hb*128]
+    # (the Ulysses send layout), source rows untouched
+    for hb in [h for h in (1, 2, H, 2 * H) if (2 * H) % h == 0]:
+        nb = 2 * H // hb
+        src = qkv.to(DEV)
+        buf = torch.full((nb, n_rows, hb * 128), 7.0, dtype=torch.bfloat16, device=DEV)
+        out = ops.qknorm_rope_(src, qw.to(DEV), kw.to(DEV), cos.to(DEV), sin.to(DEV), n_rope, H, H * 128, out=buf.permute(1, 0, 2))
+        assert torch.equal(src.cpu(), qkv)
+        want = got[:, :2 * H * 128].reshape(n_rows, nb, hb * 128).permute(1, 0, 2)
+        assert torch.equal(buf, want) and out.data_ptr() == buf.data_ptr()
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 128), (1000, 768, 256), (77, 64, 3072), (513, 1792, 256)])
