@@ -1047,7 +1047,11 @@ int launch_conv128(GemmArgs& g, hipStream_t stream) {
 // (for the other wave group: its lgkmcnt(0) + one barrier) before the issue.
 constexpr int CS_SLOT = 16384, CS_A0 = 4 * CS_SLOT, CS_ABUF = 32768, CS_LDS = CS_A0 + 2 * CS_ABUF;   // 128 KiB
 
-__global__ __launch_bounds__(512, 2) void conv128s_kernel(GemmArgs g) {
+// NARROW (Cout <= 32: conv_out, 128 -> 3 padded to 8): only the waves that own columns 0..63 (wn = 0) read fragments and issue
+// MFMAs, and only for their first 32 columns - 16 MFMAs per K-tile instead of 32 per wave and none for the other four waves; the
+// staging (the bound of this variant) and the barrier protocol are unchanged.
+template <bool NARROW>
+__device__ __forceinline__ void conv128s_body(GemmArgs g) {
     typedef F16T DT;
     typedef DT::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1150,11 +1154,20 @@ __global__ __launch_bounds__(512, 2) void conv128s_kernel(GemmArgs g) {
     vec8 ab[4][2], ax[2], wf[2][2];       // blocks 0..3 (kept for the three taps of a group), the extra block of tap 0 / tap 2
 
     auto readA = [&](vec8 (&dst)[2], int a) {
+        if (NARROW && wn != 0) return;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) dst[ks] = *reinterpret_cast<const vec8*>(smem + (a ^ (ks << 6)));
     };
     auto readB = [&](auto NHc, int wslot) {
         constexpr int NH = decltype(NHc)::value;
+        if constexpr (NARROW) {
+            if (NH != 0 || wn != 0) return;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl) wf[nl][ks] = *reinterpret_cast<const vec8*>(smem + ((w_rd ^ (ks << 6)) + wslot) + nl * 512);
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const char* base = smem + ((w_rd ^ (ks << 6)) + wslot) + NH * 4096;
@@ -1164,6 +1177,19 @@ __global__ __launch_bounds__(512, 2) void conv128s_kernel(GemmArgs g) {
     };
     auto mma = [&](auto DWc, auto NHc) {
         constexpr int DW = decltype(DWc)::value, NH = decltype(NHc)::value;
+        if constexpr (NARROW) {
+            if (NH != 0 || wn != 0) return;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int b = mi + DW - 1;
+                    const vec8& a = b < 0 || b > 3 ? ax[ks] : ab[b < 0 ? 0 : b > 3 ? 3 : b][ks];
+#pragma unroll
+                    for (int nl = 0; nl < 2; ++nl) acc[mi][nl] = DT::mfma(wf[nl][ks], a, acc[mi][nl]);     // columns 8 fq + 4 nl + r: 0..7 for fq = 0
+                }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1263,11 +1289,20 @@ __global__ __launch_bounds__(512, 2) void conv128s_kernel(GemmArgs g) {
     gemm_epilogue<DT, 4, 4, 1>(ge, acc, m0 + wm * 64 + 4 * fr, wn * 64, fq, IdRowMap(), lin * 4 + wm);
 }
 
+__global__ __launch_bounds__(512, 2) void conv128s_kernel(GemmArgs g) { conv128s_body<false>(g); }
+__global__ __launch_bounds__(512, 2) void conv128s_narrow_kernel(GemmArgs g) { conv128s_body<true>(g); }
+
 int launch_conv128s(GemmArgs& g, hipStream_t stream) {
     static HvPerDeviceOnce once;
     if (hv_set_max_lds(once, (const void*)conv128s_kernel, CS_LDS) != HV_OK) return HV_ERR_LAUNCH;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = 1;
+    if (g.N <= 32) {
+        static HvPerDeviceOnce once_n;
+        if (hv_set_max_lds(once_n, (const void*)conv128s_narrow_kernel, CS_LDS) != HV_OK) return HV_ERR_LAUNCH;
+        conv128s_narrow_kernel<<<dim3((unsigned)g.tiles_m), dim3(512), CS_LDS, stream>>>(g);
+        return hv_check_launch();
+    }
     conv128s_kernel<<<dim3((unsigned)g.tiles_m), dim3(512), CS_LDS, stream>>>(g);
     return hv_check_launch();
 }
