@@ -10,6 +10,9 @@ with torch.no_grad():
     for k, p in vae.state_dict().items():
         p.copy_(syn.synth_param("vae." + k, tuple(p.shape), 0, dev).to(p.dtype))
 vae.enable_tiling()
+import os
+if os.environ.get("VAE_STREAMS"):          # tools/trace_vae.sh: one stream, so that kernel durations in the trace are not co-run times
+    vae.decode_streams = int(os.environ["VAE_STREAMS"])
 z = syn.hashed_uniform((1, 16, T, H, W), "vae.z", 0, dev) * 1.7
 # one tile first (timing of a single decoder call)
 torch.cuda.synchronize(); t0 = time.perf_counter()
