@@ -37,7 +37,10 @@ constexpr int BM = 256, BK = 64;                 // BN is a template parameter: 
 constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB per A tile (W tile: BN * BK * 2)
 template <int BN> constexpr int stage_bytes() { return TILE_BYTES + BN * BK * 2; }
 template <int BN> constexpr int lds_bytes() { return 2 * stage_bytes<BN>(); }   // double buffered: 128 KiB (BN=256) / 96 KiB (BN=128)
-constexpr int GROUP_M = 4;
+#ifndef HV_GROUP_M
+#define HV_GROUP_M 4
+#endif
+constexpr int GROUP_M = HV_GROUP_M;
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
