@@ -96,3 +96,23 @@ def test_first_tile_extremes(ops):
 def test_shapes_and_partials(ops, n_q, n_kv, H):
     q, k, v = U((n_q, H, 128), "p.q", 2.0), U((n_kv, H, 128), "p.k"), U((n_kv, H, 128), "p.v")
     _check(ops, q, k, v, H)
+
+
+def test_run_to_run_identical(ops):
+    """The kernels pin inline-asm VALU instructions (row-sum adds, row-max v_max3) next to MFMAs and v_exp_f32 whose results they read;
+    the compiler pads hazards only for instructions it can see.  A too-early read shows up as run-to-run different sums (that is how
+    the 16x16x32 variant's first schedule was caught), so: same inputs, several runs, identical bits - default kernel and the variants
+    with their own schedules."""
+    n_q, n_kv, H = 1000, 12345, 2
+    q, k, v = U((n_q, H, 128), "d.q", 2.0), U((n_kv, H, 128), "d.k"), U((n_kv, H, 128), "d.v")
+    for ver in (None, "8", "9"):
+        if ver is None:
+            os.environ.pop("HV_ATTN_VER", None)
+        else:
+            os.environ["HV_ATTN_VER"] = ver
+        try:
+            first = _run(ops, q, k, v, H).clone()
+            for _ in range(5):
+                assert torch.equal(_run(ops, q, k, v, H), first), ver
+        finally:
+            os.environ.pop("HV_ATTN_VER", None)
