@@ -69,6 +69,13 @@ def test_attention_production_shape_sampled_rows(ops):
         got = cat[rows.to(DEV), c].float().cpu()
         assert float(ref.abs().max()) > 0.3                      # the comparison is not vacuous
         torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=8e-3)
+    # the whole chip busy, every CU on its 44th workgroup in a row: the launch must reproduce itself bit for bit (a hazard between an
+    # inline-asm instruction and the v_exp_f32 / MFMA it reads from would show up as run-to-run noise in the row sums)
+    first = cat[:CU1, :D].clone()
+    ops.attn_fwd(qkv[:CU1, :D], qkv[:CU1, D:2 * D], qkv[:CU1, 2 * D:], cat[:CU1, :D], H)
+    torch.cuda.synchronize()
+    assert torch.equal(cat[:CU1, :D], first)
+    del first
     # second segment: rows [CU1, S) attend among themselves only
     r2 = torch.tensor([0, 100, S - CU1 - 1])
     k = qkv[CU1:, D:D + 128].float().cpu()
