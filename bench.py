@@ -42,7 +42,10 @@ def cpu_baseline(f_step, seconds_budget=30.0):
     """the oracle (CPU port of the reference path, fp32 eager, all host threads) timed on
     (i) BASELINE.json configs[0] exactly (tiny DiT, one denoise step), (ii) one double + one single block at full width d=3072,
     S=4,096+256 tokens - the leg `value` is FLOP-scaled from (stated as an extrapolation) - and (iii) one reduced VAE decoder
-    tile.  Bounded: about 10-30 s of CPU work on the GPU box's host cores."""
+    tile.  Bounded: about 10-30 s of CPU work on the GPU box's host cores.
+    The oracle outputs of leg (ii) are not thrown away: the same two blocks run on the GPU (HIP kernels, bf16) on the same
+    bf16-rounded weights and inputs and the distance is reported as `block_check` and asserted (oracle = checker, never the thing
+    measured as `value`)."""
     import torch
     from hunyuanvideo_efficiency_amd import synthetic as syn
     from oracle import dit_ref as R
@@ -65,27 +68,36 @@ def cpu_baseline(f_step, seconds_budget=30.0):
         # (ii) one double + one single block, d=3072, S=4096+256
         cfg = syn.DiTConfig(mm_double_blocks_depth=1, mm_single_blocks_depth=1)
         d, s_img, s_txt = cfg.hidden_size, 4096, 256
+        from tests.oracle_checks import fullwidth_block_inputs, fullwidth_blocks
         sd = {}
         for k, shp in syn.dit_param_shapes(cfg).items():
             if k.startswith("double_blocks.0.") or k.startswith("single_blocks.0."):
-                sd[k] = syn.synth_param(k, shp, 0, gen_dev).cpu()
-        img = syn.hashed_uniform((1, s_img, d), "cpu.img", 0) * 1.7
-        txt = syn.hashed_uniform((1, s_txt, d), "cpu.txt", 0) * 1.7
-        vec = syn.hashed_uniform((1, d), "cpu.vec", 0) * 0.5
+                sd[k] = syn.synth_param(k, shp, 0, gen_dev).to(torch.bfloat16).float().cpu()      # the values the GPU model holds
+        img, txt, vec = fullwidth_block_inputs(cfg, s_img, s_txt)
         cos, sin = R.rope_tables([4, 32, 32], cfg.rope_dim_list, 256.0)
         cu = torch.tensor([0, s_img + 11, s_img + s_txt], dtype=torch.int32)
         f_sample = 2 * (24 * d * d * (s_img + s_txt) + 4 * (s_img + s_txt) ** 2 * d)
         reps, t0 = 0, time.perf_counter()
         while True:
             io, to = R.double_block(sd, "double_blocks.0.", img, txt, vec, cu, cos, sin, cfg.heads_num, R.FP32)
-            R.single_block(sd, "single_blocks.0.", torch.cat([io, to], 1), vec, s_txt, cu, cos, sin, cfg.heads_num, R.FP32)
+            so = R.single_block(sd, "single_blocks.0.", torch.cat([img, txt], 1), vec, s_txt, cu, cos, sin, cfg.heads_num, R.FP32)
             reps += 1
             el = time.perf_counter() - t0
             if el > seconds_budget * 0.5 or reps >= 4:
                 break
         sec_per_sample = el / reps
         cpu_flops = f_sample / sec_per_sample
-        del sd, img, txt
+        del sd
+        # the same blocks on the GPU against the fp32 oracle outputs just timed: bf16 drift bound (the tight, bf16-emulated
+        # comparison is tests/test_gpu_fullsize_c5.py::test_blocks_shipped_width_vs_oracle)
+        block_check = None
+        if torch.cuda.is_available():
+            r = fullwidth_blocks("cuda", s_img=s_img, s_txt=s_txt, oracle_out=(io, to, so))
+            errs = {k: float((g - o).abs().max() / o.abs().max()) for k, (g, o) in r.items()}
+            block_check = {"what": "GPU double+single block (d=3072, 24 heads, S=4096+256, bf16) vs the fp32 oracle outputs of the "
+                                   "timed CPU sample: max |diff| / max |ref|", **errs, "tol": 3e-2}
+            assert max(errs.values()) < 3e-2, f"GPU blocks deviate from the oracle: {errs}"
+        del img, txt, io, to, so
         # (iii) one reduced VAE decoder tile: channels (32,64,128,128), latent 5x16x16 -> [3,17,128,128]
         boc = (32, 64, 128, 128)
         vsd = syn.synth_vae_state_dict(boc, seed=0)
@@ -99,7 +111,7 @@ def cpu_baseline(f_step, seconds_budget=30.0):
                       f"{sec_per_sample:.2f} s each = {cpu_flops / 1e12:.3f} TFLOP/s; config 1 (tiny DiT, 1 step) "
                       f"{legs['config1_tiny_step_s']:.3f} s"
                       f"; reduced VAE decoder tile (32,64,128,128) 5x16x16 latent {legs['vae_reduced_tile_s']:.2f} s",
-            **legs}
+            "block_check": block_check, **legs}
 
 
 def launch_ranks(n: int) -> int:
@@ -151,6 +163,9 @@ def main():
     ap.add_argument("--fp8-mfma", action="store_true", help="with --use-fp8: run the block linears on the CDNA4 FP8 matrix cores "
                     "(v_mfma_scale_f32_16x16x128_f8f6f4; activations quantised per token to e4m3) instead of dequantising the weights "
                     "to bf16 per call - an opt-in approximation beyond the reference's weight-only FP8 (tests/test_gpu_fp8_mfma.py)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (544x960x65f, 720p x 257f, FP8-MFMA) that a "
+                    "default single-GPU 720p129f run appends after its timed leg")
+    ap.add_argument("--secondary-budget", type=float, default=150.0, help="wall-clock seconds the secondary workloads may take in total")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-by-`value`) VAE tiled decode of the same video")
     a = ap.parse_args()
 
@@ -207,37 +222,104 @@ def main():
             parallelize_transformer_module(model, None)
         else:
             parallelize_transformer_module(model, dist.group.WORLD)
-    x, ts, tm, ts2 = syn.synth_dit_inputs(cfg, (T, H, W), s_txt, 11, seed=42, device=dev)
-    ts = ts.to(torch.bfloat16)
-    cos, sin = get_nd_rotary_pos_embed(cfg.rope_dim_list, [T, H // 2, W // 2], theta=256, use_real=True, device=dev)
     guidance = (torch.tensor([6.0], dtype=torch.float32, device=dev).to(torch.bfloat16) * 1000.0)
-    n_total = a.warmup + a.steps
-    sched = FlowMatchDiscreteScheduler(shift=7.0, reverse=True, solver="euler")
-    sched.set_timesteps(max(n_total, 50), device=dev)
-    lat = x.clone()
-
-    def one_step(i, lat):
-        t = sched.timesteps[i]
-        v = model(lat, t.repeat(1), text_states=ts, text_mask=tm, text_states_2=ts2, freqs_cos=cos, freqs_sin=sin,
-                  guidance=guidance, return_dict=True)["x"]
-        return sched.step(v, t, lat, return_dict=False)[0]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for i in range(a.warmup):
-            lat = one_step(i, lat)
-        barrier()
-        ops.PROFILE_ATTN = []          # HIP events around every main-segment attention launch, on the launch stream
-        t0 = time.perf_counter()
-        for i in range(a.warmup, n_total):
-            lat = one_step(i, lat)
-        barrier()
-        elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
+    def run_leg(workload, steps, warmup):
+        """W untimed + K timed denoise steps of `workload` on the model as it stands; returns (seconds for the K steps on this rank,
+        [(ms, flop)] of the main-segment attention launches inside the timed region, final latents)."""
+        lt, lh, lw = WORKLOADS[workload]
+        x, ts, tm, ts2 = syn.synth_dit_inputs(cfg, (lt, lh, lw), s_txt, 11, seed=42, device=dev)
+        ts = ts.to(torch.bfloat16)
+        cos, sin = get_nd_rotary_pos_embed(cfg.rope_dim_list, [lt, lh // 2, lw // 2], theta=256, use_real=True, device=dev)
+        n_total = warmup + steps
+        sched = FlowMatchDiscreteScheduler(shift=7.0, reverse=True, solver="euler")
+        sched.set_timesteps(max(n_total, 50), device=dev)
+        lat = x.clone()
+
+        def one_step(i, lat):
+            t = sched.timesteps[i]
+            v = model(lat, t.repeat(1), text_states=ts, text_mask=tm, text_states_2=ts2, freqs_cos=cos, freqs_sin=sin,
+                      guidance=guidance, return_dict=True)["x"]
+            return sched.step(v, t, lat, return_dict=False)[0]
+
+        with torch.no_grad():
+            for i in range(warmup):
+                lat = one_step(i, lat)
+            barrier()
+            ops.PROFILE_ATTN = []          # HIP events around every main-segment attention launch, on the launch stream
+            t0 = time.perf_counter()
+            for i in range(warmup, n_total):
+                lat = one_step(i, lat)
+            barrier()
+            el = time.perf_counter() - t0
+        prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
+        att = [(e0.elapsed_time(e1), 4.0 * nq * nkv * 128 * nh) for e0, e1, nq, nkv, nh in prof if nkv > 1024 or workload == "tiny"]
+        assert bool(torch.isfinite(lat).all()), f"non-finite latents ({workload})"
+        return el, att, lat
+
+    elapsed, att, lat = run_leg(a.workload, a.steps, a.warmup)
+    att_ms, att_flop = [m for m, _ in att], [f for _, f in att]
+
+    # Secondary workloads (BASELINE.json configs 2, 5 and 4) on the same model, AFTER the timed headline leg and never part of
+    # `value`: a few steps each inside a stated wall-clock budget (what does not fit is skipped and says so).
+    secondary = []
+    if world == 1 and a.workload == "720p129f" and not a.no_secondary and not a.use_fp8 and not a.force_sp:
+        budget_s, t_sec0 = a.secondary_budget, time.perf_counter()
+        ms129 = elapsed / a.steps * 1e3
+
+        def leg_entry(workload, steps, warmup, dtype, note=None):
+            el, at, _ = run_leg(workload, steps, warmup)
+            lt, lh, lw = WORKLOADS[workload]
+            si = lt * (lh // 2) * (lw // 2)
+            fs = step_flops(si, s_txt, cfg.hidden_size, cfg.mm_double_blocks_depth, cfg.mm_single_blocks_depth)
+            ms = el / steps * 1e3
+            am = sum(m for m, _ in at) / max(len(at), 1)
+            af = sum(f for _, f in at) / max(len(at), 1)
+            tf = af / (am * 1e-3) / 1e12 if at else 0.0
+            e = {"workload": workload, "steps": steps, "warmup": warmup, "ms_per_step": ms, "dtype": dtype,
+                 "step_pflop": fs / 1e15, "step_mfma_frac": fs / (ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
+                 "roofline": {"kernel": "attn_fwd_kernel (main segment)", "bound": "mfma", "achieved": tf, "peak": PEAK_BF16_TFLOPS,
+                              "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "avg_launch_ms": am, "launches": len(at)}}
+            if note:
+                e["note"] = note
+            return e
+
+        # estimated cost of each leg from the headline leg's measured step time (FLOP-scaled), checked against what is left
+        plan = [("544p65f", 3, 1, "bf16", 4 * ms129 * 1.375 / 12.07 / 1e3 + 2, None),
+                ("720p257f", 1, 0, "bf16", ms129 * 43.64 / 12.07 / 1e3 + 3,
+                 "one timed step, no separate warm-up step (kernels and weights are warm from the previous legs; the S = 234,256 "
+                 "workspace is allocated before the clock starts)")]
+        for wl, st, wu, dt, est, note in plan:
+            left = budget_s - (time.perf_counter() - t_sec0)
+            if est > left:
+                secondary.append({"workload": wl, "skipped": f"estimated {est:.0f} s > {left:.0f} s left of the {budget_s:.0f} s budget"})
+                continue
+            if wl == "720p257f":
+                model._workspace(65 * 45 * 80, s_txt, dev)
+            secondary.append(leg_entry(wl, st, wu, dt, note))
+        model._ws = None
+        est = 3 * ms129 / 1e3 + 15
+        left = budget_s - (time.perf_counter() - t_sec0)
+        if est > left:
+            secondary.append({"workload": "720p129f fp8-mfma", "skipped": f"estimated {est:.0f} s > {left:.0f} s left of the {budget_s:.0f} s budget"})
+        else:
+            from hunyuanvideo_efficiency_amd.modules.fp8_optimization import convert_fp8_linear, enable_fp8_mfma
+            convert_fp8_linear(model, None, torch.bfloat16)
+            enable_fp8_mfma(model)
+            e = leg_entry("720p129f", 2, 1, "bf16+fp8(e4m3) linears",
+                          "BASELINE.json configs[3] on the CDNA4 FP8 matrix cores (--use-fp8 --fp8-mfma): e4m3 weights, activations "
+                          "quantised per token, bf16 attention.  Tested tolerance (tests/test_gpu_fp8_mfma.py): GEMM == the "
+                          "quantisation-aware oracle to 1 bf16 ulp (rtol 2^-7, atol 2e-2), quantisers bit-exact, tiny-model output "
+                          "within 3e-2 of range of that oracle and within 1e-1 of range of the reference's weight-only FP8 semantics")
+            e["workload"] = "720p129f fp8-mfma"
+            secondary.append(e)
+        model._ws = None
+        torch.cuda.empty_cache()
     # end-to-end leg (reported beside `value`, never part of it): VAE tiled decode of this video's latents on rank 0's GPU
     vae_s = None
     if not tiny and not a.no_vae:
@@ -263,14 +345,8 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    assert bool(torch.isfinite(lat).all()), "non-finite latents"
 
-    # dominant kernel: flash attention (main segment launches only: n_kv > 1024)
-    att_ms, att_flop = [], []
-    for e0, e1, nq, nkv, nh in prof:
-        if nkv > 1024 or tiny:
-            att_ms.append(e0.elapsed_time(e1))
-            att_flop.append(4.0 * nq * nkv * 128 * nh)
+    # dominant kernel: flash attention (main segment launches only: n_kv > 1024) - att_ms / att_flop from the headline leg
     if rank == 0:
         f_step = step_flops(s_img, s_txt, cfg.hidden_size, cfg.mm_double_blocks_depth, cfg.mm_single_blocks_depth)
         ms_per_step = elapsed / a.steps * 1e3
@@ -281,7 +357,7 @@ def main():
         # and shape (separate --pmc passes; FETCH_SIZE x2 gfx950 correction), newest round first; `traffic_source` names the file
         traffic, traffic_note, traffic_source = None, None, None
         if world == 1 and a.workload == "720p129f":
-            for rnd in ("r02", "r01"):
+            for rnd in ("r03", "r02", "r01"):
                 tf = os.path.join(ROOT, "profiles", rnd, "attn_traffic.json")
                 if os.path.exists(tf):
                     tj = json.load(open(tf))
@@ -311,6 +387,8 @@ def main():
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note,
                          "launches": len(att_ms), "avg_launch_ms": avg_ms, "flop_per_launch": avg_flop},
         }
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(f_step)
         real_stdout.write(json.dumps(out) + "\n")

@@ -15,6 +15,7 @@ side is one HBM-bound strided-copy kernel (hv_copy3d_bf16) and the attention is 
 received buffers in place (no concatenation)."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -73,13 +74,28 @@ class UlyssesLongContextAttention:
     _default_ring_group = None
     MIN_SEG_ROWS = 256       # attend_async: no segment of the output exchange smaller than one GEMM tile of rows (tests lower it)
 
-    def __init__(self, group=None, kernels=None, ring_group=None):
+    # Exchange variants for P > 1, selectable per object or by environment so that the first >= 2-GPU run can A/B them.  The
+    # DEFAULTS are the forms that have the longest record (gloo, lazy-collective proxy, host-staged one-card runs): ONE
+    # all_to_all_single for the whole output + one unpack, q/k packed by hv_copy3d.  The segmented / scatter-packed forms have
+    # never run on RCCL (no multi-GPU box in this build's sessions) and stay opt-in until tests/test_gpu_rccl_multirank.py has
+    # passed with them:
+    #   HV_SP_NSEG=<n>            output exchange cut into n row segments overlapped with the out-projection (default 1)
+    #   HV_SP_OUT_EXCHANGE=a2a|p2p  how a SEGMENT travels: "a2a" (default) = pack + all_to_all_single + unpack per segment;
+    #                             "p2p" = one isend/irecv pair per peer, coalesced by batch_isend_irecv, no staging copies
+    #   HV_SP_SCATTER_PACK=1      q/k chunks stored straight into the send layout by hv_qknorm_rope_scatter_bf16 (pack_dst)
+    def __init__(self, group=None, kernels=None, ring_group=None, nseg: Optional[int] = None, out_exchange: Optional[str] = None,
+                 scatter_pack: Optional[bool] = None):
         self.group = group if group is not None else UlyssesLongContextAttention._default_group
         self.ring_group = ring_group if ring_group is not None else UlyssesLongContextAttention._default_ring_group
         self.k = kernels or _HipKernels
         self._bufs = {}
         self._parts = None
         self.min_seg_rows = UlyssesLongContextAttention.MIN_SEG_ROWS
+        self.nseg = int(os.environ.get("HV_SP_NSEG", "1")) if nseg is None else int(nseg)
+        self.out_exchange = (os.environ.get("HV_SP_OUT_EXCHANGE", "a2a") if out_exchange is None else out_exchange).lower()
+        if self.out_exchange not in ("a2a", "p2p"):
+            raise ValueError(f"HV_SP_OUT_EXCHANGE must be a2a or p2p, got {self.out_exchange!r}")
+        self.scatter_pack = (os.environ.get("HV_SP_SCATTER_PACK", "0") == "1") if scatter_pack is None else bool(scatter_pack)
 
     @classmethod
     def set_sequence_parallel_group(cls, group, ring_group=None):
@@ -203,7 +219,7 @@ class UlyssesLongContextAttention:
         """P > 1: the send buffer of the q / k / v exchange as a [s_loc, P, w] view (row r, peer p at send[p][r][:]) - a producer that
         can store by head block (ops.qknorm_rope_(..., out=)) writes the packed layout itself and calls send_packed(); None for P = 1."""
         P, rank, s_loc, n_j, heads, w = self._geo
-        if P == 1:
+        if P == 1 or not self.scatter_pack:
             return None
         send = self._buf("send_" + which, (P * s_loc, w), self._bufs["qf"].device)
         return send.view(P, s_loc, w).permute(1, 0, 2)
@@ -239,17 +255,22 @@ class UlyssesLongContextAttention:
         for _, _, finish in self.attend_async(out, ld_out, nseg=1):
             finish()
 
-    def attend_async(self, out: torch.Tensor, ld_out: int, nseg: int = 2):
+    def attend_async(self, out: torch.Tensor, ld_out: int, nseg: Optional[int] = None):
         """Attention over all tokens for this rank's heads, then the OUTPUT exchange cut into `nseg` row segments of the local
         image tokens so that it overlaps the out-projection GEMM that consumes it (north_star: "all-to-all ... overlapped with the
         per-head GEMMs"): every segment is its own asynchronous exchange (started at once, RCCL runs them on its stream in order);
         the caller walks the returned [(row_lo, row_hi, finish)] list - finish() makes the compute stream wait for THAT segment
         and unpacks it into out[row_lo:row_hi] - and launches the GEMM of those rows while the next segment is still on the wire.
         The last segment also covers the joint (text) rows [s_loc, s_loc + n_j).
-        A segment of rows [r0, r1) is, per peer p, the contiguous slice of[p*s_loc + r0 : p*s_loc + r1] -> recv[p][r0:r1]: one
-        point-to-point pair per peer (`batch_isend_irecv`, coalesced by RCCL into one grouped launch = an all-to-all of that
-        segment; every xGMI link carries exactly its pair's bytes)."""
+        A segment of rows [r0, r1) is, per peer p, the contiguous slice of[p*s_loc + r0 : p*s_loc + r1] -> recv[p][r0:r1].
+        out_exchange "p2p": one point-to-point pair per peer (`batch_isend_irecv`, coalesced by RCCL into one grouped launch = an
+        all-to-all of that segment; every xGMI link carries exactly its pair's bytes), no staging.  "a2a": the per-peer slices
+        are packed into one contiguous [P][r1-r0][w] staging buffer (hv_copy3d), exchanged by all_to_all_single and unpacked
+        from its receive twin.  nseg None -> this object's setting (HV_SP_NSEG, default 1: the whole output in one
+        all_to_all_single)."""
         P, rank, s_loc, n_j, heads, w = self._geo
+        if nseg is None:
+            nseg = self.nseg
         for wk in self._works:
             wk.wait()                       # the compute stream waits for the q/k/v exchanges (no host sync)
         self._works = []
@@ -273,6 +294,14 @@ class UlyssesLongContextAttention:
             if r0 == 0 and r1 == s_loc:
                 seg_works.append([dist.all_to_all_single(recv, of[:s_img], group=self.group, async_op=True)])
                 continue
+            if self.out_exchange == "a2a":
+                # one staging pair per segment (distinct buffers: the segments' exchanges are all in flight at once)
+                n = r1 - r0
+                sseg = self._buf(f"seg_send_{len(seg_works)}", (P * n, w), out.device)
+                rseg = self._buf(f"seg_recv_{len(seg_works)}", (P * n, w), out.device)
+                self.k.copy3d(of[r0:], sseg, P, n, w, s_loc * w, w, n * w, w)
+                seg_works.append([dist.all_to_all_single(rseg, sseg, group=self.group, async_op=True)])
+                continue
             p2p = []
             for p in range(P):
                 if p == rank:
@@ -286,11 +315,15 @@ class UlyssesLongContextAttention:
             recv_t = self._buf("recv_t", (P * n_j, w), out.device)
             txt_work = dist.all_gather_into_tensor(recv_t, of[s_img:].contiguous(), group=self.group, async_op=True)
 
-        def make_finish(r0, r1, works, last):
+        def make_finish(r0, r1, works, last, idx):
             def finish():
                 for wk in works:
                     wk.wait()
-                if P == 1 or not (r0 == 0 and r1 == s_loc):
+                if P > 1 and not (r0 == 0 and r1 == s_loc) and self.out_exchange == "a2a":
+                    # unpack this segment's receive staging: out[r0 + r][p*w + c] = rseg[p][r][c]
+                    n = r1 - r0
+                    self.k.copy3d(b[f"seg_recv_{idx}"], out[r0:], P, n, w, n * w, w, w, ld_out)
+                elif P == 1 or not (r0 == 0 and r1 == s_loc):
                     # this rank's own slice never crosses a link: it is unpacked straight from the attention output
                     self.k.copy3d(of[rank * s_loc + r0:], out[r0:, rank * w:], 1, r1 - r0, w, 0, w, 0, ld_out)
                     if P > 1:
@@ -308,7 +341,7 @@ class UlyssesLongContextAttention:
         segs = []
         for i, ((r0, r1), works) in enumerate(zip(zip(bounds[:-1], bounds[1:]), seg_works)):
             last = i == len(seg_works) - 1
-            segs.append((r0, (s_loc + n_j) if last else r1, make_finish(r0, r1, works, last)))
+            segs.append((r0, (s_loc + n_j) if last else r1, make_finish(r0, r1, works, last, i)))
         return segs
 
     # ------------------------------------------------------------------ reference hook signature

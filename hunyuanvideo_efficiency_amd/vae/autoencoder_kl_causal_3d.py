@@ -28,6 +28,17 @@ from .. import vae_ops as V
 F16 = torch.float16
 
 
+dist = None      # torch.distributed, imported on first use (tests/test_lazy_collectives_gloo.py substitutes a lazy-completion proxy)
+
+
+def _dist():
+    global dist
+    if dist is None:
+        import torch.distributed as _d
+        dist = _d
+    return dist
+
+
 def _r(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -571,9 +582,19 @@ class AutoencoderKLCausal3D(nn.Module):
     # which decodes every tile on every rank).  Tiles are independent until the blend: each rank decodes its share, the decoded
     # tiles are all-gathered (one RCCL all-gather per round of P tiles, in flight while the next round decodes), and every rank
     # runs the reference's blend loops over the complete set, so decode() still returns the whole video on every rank.
-    def enable_tile_parallel(self, group=None, enable: bool = True):
+    def enable_tile_parallel(self, group=None, enable: bool = True, gather: Optional[str] = None):
+        """gather (or HV_VAE_TILE_GATHER): "all" (default) - every decoded tile is all-gathered, every rank blends and returns the
+        whole video (what the reference's callers get, since it decodes everything everywhere); "rank0" - tiles are gathered to
+        group rank 0 only, which blends and returns the video; the other ranks return zeros of the video's shape (the reference's
+        driver saves on rank 0 only: sample_video.py).  1/P of the receive traffic per rank; never timed on hardware - both stay
+        selectable so the first multi-GPU run can A/B them."""
         self._tp_enabled = enable
         self._tp_group = group
+        import os
+        g = (gather or os.environ.get("HV_VAE_TILE_GATHER", "all")).lower()
+        if g not in ("all", "rank0"):
+            raise ValueError(f"tile gather mode must be 'all' or 'rank0', got {g!r}")
+        self._tp_gather = g
 
     def _spatial_views(self, z4):
         ov = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
@@ -612,7 +633,7 @@ class AutoencoderKLCausal3D(nn.Module):
         return plan
 
     def _decode_tiles_sharded(self, z4, group):
-        import torch.distributed as dist
+        dist = _dist()
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         views = list(self._tile_views(z4))
         tc = self.time_compression_ratio
@@ -620,7 +641,9 @@ class AutoencoderKLCausal3D(nn.Module):
         plan = self._assign_tiles([v.shape[1] * v.shape[2] * v.shape[3] for v in views], world)
         rounds = max(len(p) for p in plan)
         max_rows = max(t * h * w for t, h, w in dims)
-        gathered = torch.empty(rounds, world, max_rows, 8, dtype=F16, device=z4.device)
+        to_root = getattr(self, "_tp_gather", "all") == "rank0"
+        root = dist.get_global_rank(group, 0) if group is not None else 0
+        gathered = torch.empty(rounds, world, max_rows, 8, dtype=F16, device=z4.device) if (rank == 0 or not to_root) else None
         mine = torch.zeros(rounds, max_rows, 8, dtype=F16, device=z4.device)
         works = []
         for r in range(rounds):
@@ -629,9 +652,15 @@ class AutoencoderKLCausal3D(nn.Module):
                 buf, T, H, W = self._decode_tile(views[k])
                 assert (T, H, W) == dims[k] and buf.shape[1] == 8
                 mine[r, :buf.shape[0]].copy_(buf)
-            works.append(dist.all_gather_into_tensor(gathered[r].view(world * max_rows, 8), mine[r], group=group, async_op=True))
+            if to_root:
+                works.append(dist.gather(mine[r], [gathered[r, p] for p in range(world)] if rank == 0 else None, dst=root, group=group,
+                                         async_op=True))
+            else:
+                works.append(dist.all_gather_into_tensor(gathered[r].view(world * max_rows, 8), mine[r], group=group, async_op=True))
         for w in works:
             w.wait()
+        if gathered is None:
+            return None          # "rank0" mode, not the root: nothing to blend here
         out = [None] * len(views)
         for p in range(world):
             for r, k in enumerate(plan[p]):
@@ -750,6 +779,10 @@ class AutoencoderKLCausal3D(nn.Module):
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(self._tp_group) > 1:
                 self._tile_queue = self._decode_tiles_sharded(z4, self._tp_group)
+                if self._tile_queue is None:
+                    # gather-to-rank-0 mode on a non-root rank: the video lives on rank 0; same shape, zeros, here
+                    tc = self.time_compression_ratio
+                    return torch.zeros(1, 3, (z4.shape[1] - 1) * tc + 1, z4.shape[2] * 8, z4.shape[3] * 8, dtype=F16, device=z4.device)
         if self._tile_queue is None and (self.use_temporal_tiling or self.use_spatial_tiling):
             self._tile_queue = self._decode_tiles_concurrent(z4)
         try:

@@ -40,3 +40,45 @@ def tiny_step_vs_oracle(device="cuda:0", latent_thw=(5, 16, 16), txt_len=32, n_v
     if not (err_v < 3e-2 and err_x < 3e-2):
         raise AssertionError(f"tiny denoise step differs from the oracle: noise_pred {err_v:.3e}, latents {err_x:.3e}")
     return max(err_v, err_x)
+
+
+def fullwidth_blocks(device="cuda:0", prec=None, s_img=4096, s_txt=256, n_valid=11, grid=(4, 32, 32), oracle_out=None):
+    """One MMDoubleStreamBlock + one MMSingleStreamBlock at the SHIPPED width (d = 3072, 24 heads, mlp 12288) on S = s_img + s_txt
+    tokens: the GPU blocks through their reference call surfaces and the oracle (precision `prec`, default the bf16-emulated
+    contract) on the same bf16-rounded weights and inputs.  Returns {name: (gpu fp32 cpu tensor, oracle tensor)} for
+    double_img / double_txt / single.  `oracle_out`: (io, to, so) already computed by the caller with the SAME weights and inputs
+    (bench.py's cpu_baseline leg times exactly that computation) - then only the GPU side runs here."""
+    from oracle import dit_ref as R
+    prec = prec or R.Prec(True)
+    cfg = syn.DiTConfig(mm_double_blocks_depth=1, mm_single_blocks_depth=1)
+    model = build_model(cfg, device)
+    img, txt, vec = fullwidth_block_inputs(cfg, s_img, s_txt)
+    cos, sin = R.rope_tables(list(grid), cfg.rope_dim_list, 256.0)
+    cu = torch.tensor([0, s_img + n_valid, s_img + s_txt], dtype=torch.int32)
+    bf = lambda t: t.to(device).to(torch.bfloat16)
+    S = s_img + s_txt
+    with torch.no_grad():
+        io, to = model.double_blocks[0](bf(img), bf(txt), bf(vec), cu, cu, S, S, (cos.to(device), sin.to(device)))
+        io, to = io.float().cpu(), to.float().cpu()
+        so = model.single_blocks[0](bf(torch.cat([img, txt], 1)), bf(vec), s_txt, cu, cu, S, S, (cos.to(device), sin.to(device)))
+        so = so.float().cpu()
+    torch.cuda.synchronize()
+    if oracle_out is None:
+        sd = {k: p.float().cpu() for k, p in model.state_dict().items()
+              if k.startswith("double_blocks.0.") or k.startswith("single_blocks.0.")}
+        rio, rto = R.double_block(sd, "double_blocks.0.", img, txt, vec, cu, cos, sin, cfg.heads_num, prec)
+        rso = R.single_block(sd, "single_blocks.0.", torch.cat([img, txt], 1), vec, s_txt, cu, cos, sin, cfg.heads_num, prec)
+    else:
+        rio, rto, rso = oracle_out
+    del model
+    return {"double_img": (io, rio), "double_txt": (to, rto), "single": (so, rso)}
+
+
+def fullwidth_block_inputs(cfg, s_img=4096, s_txt=256):
+    """bf16-representable inputs of fullwidth_blocks (and of bench.py's cpu_baseline sample): residual streams of range ~ +-1.7"""
+    r = lambda t: t.to(torch.bfloat16).float()
+    d = cfg.hidden_size
+    img = r(syn.hashed_uniform((1, s_img, d), "cpu.img", 0) * 1.7)
+    txt = r(syn.hashed_uniform((1, s_txt, d), "cpu.txt", 0) * 1.7)
+    vec = r(syn.hashed_uniform((1, d), "cpu.vec", 0) * 0.5)
+    return img, txt, vec

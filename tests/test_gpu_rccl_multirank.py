@@ -2,8 +2,8 @@
 substituted - `all_to_all_single` (async, waited on the compute stream), `all_gather` / `all_gather_into_tensor`,
 `batch_isend_irecv` ring hops on nccl sub-groups, the tile-parallel VAE all-gather - i.e. BASELINE.json configs 3 and 5 in
 miniature.  Property (reference tests/test_attention.py:90-109 and hyvideo/inference.py:157-176): the sharded forward,
-gathered, equals the unsharded forward on the same weights and inputs; the exchange-level op equals unsharded attention at
-rtol = atol = 1e-3... widened to bf16 round-off of the merge (2 ulp) for the ring.
+gathered, equals the unsharded forward on the same weights and inputs; the exchange-level op equals unsharded attention at the
+reference's own bar, rtol = atol = 1e-3 (tests/test_attention.py:109).
 
 Also: `python bench.py --gpus 2 --workload tiny` from a cold shell (no RANK in the environment) must launch its own ranks and
 print one JSON line."""
@@ -47,13 +47,23 @@ def _worker(rank, world, port, outdir, U, R):
         out = sp(None, q[:, sl], k[:, sl], v[:, sl], joint_tensor_query=q[:, s_img:], joint_tensor_key=k[:, s_img:],
                  joint_tensor_value=v[:, s_img:], joint_strategy="rear")
         exp = torch.cat([full[sl], full[s_img:]], 0).reshape(1, s_loc + n_txt, H, 128)
-        torch.testing.assert_close(out.float(), exp.float(), rtol=2 ** -7, atol=2e-3)
+        torch.testing.assert_close(out.float(), exp.float(), rtol=1e-3, atol=1e-3)      # /root/reference/tests/test_attention.py:109
         # ---- model level: sharded forward == unsharded forward (twice: buffers and async handles are reused across steps)
         cfg = syn.DiTConfig(hidden_size=512, heads_num=4, mm_double_blocks_depth=1, mm_single_blocks_depth=2)
         base_model = builders.build_model(cfg, dev)
-        sp_model = builders.build_model(cfg, dev)
-        parallelize_transformer_module(sp_model, None)
-        for thw, txt_len, n_valid in (((5, 16, 8 * world), 32, 11), ((3, 8 * world + 2, 8 * world), 32, 32)):
+        # the default exchange (one all_to_all_single per tensor, copy3d pack) and the opt-in forms (HV_SP_*: segmented output
+        # exchange as a2a staging / point-to-point pairs, scatter-packed q/k) - the first >= 2-GPU run exercises all of them
+        UlyssesLongContextAttention.MIN_SEG_ROWS = 16
+        sp_models = []
+        for env in (dict(HV_SP_NSEG="1", HV_SP_OUT_EXCHANGE="a2a", HV_SP_SCATTER_PACK="0"),
+                    dict(HV_SP_NSEG="2", HV_SP_OUT_EXCHANGE="a2a", HV_SP_SCATTER_PACK="1"),
+                    dict(HV_SP_NSEG="2", HV_SP_OUT_EXCHANGE="p2p", HV_SP_SCATTER_PACK="1")):
+            os.environ.update(env)
+            m = builders.build_model(cfg, dev)
+            parallelize_transformer_module(m, None)
+            sp_models.append(m)
+        for (thw, txt_len, n_valid), sp_model in [(c, m) for c in (((5, 16, 8 * world), 32, 11), ((3, 8 * world + 2, 8 * world), 32, 32))
+                                                  for m in sp_models]:
             x, ts, tm, ts2 = syn.synth_dit_inputs(cfg, thw, txt_len, n_valid, seed=1)
             T, Hh, W = thw
             cos, sin = get_nd_rotary_pos_embed(cfg.rope_dim_list, [T, Hh // 2, W // 2], theta=256, use_real=True)
@@ -112,14 +122,24 @@ def test_sequence_parallel_forward_real_rccl(U, R, tmp_path):
     assert all(v == "ok" for v in results.values()), results
 
 
-@needs2
-def test_bench_launches_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2` from a cold shell: the parent never touches the GPU, starts 2 ranks, rank 0 prints the line."""
+def _bench_launcher_helper(_idx, outdir):
+    """Runs in a fork-server child that has never touched the GPU: IT may start bench.py by fork+exec (the pytest process, which
+    has initialised HIP by the time this test runs, may not - tests/conftest.py:14-17)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "2",
                         "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-3000:]
-    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    with open(os.path.join(outdir, "bench.json"), "w") as f:
+        json.dump({"returncode": p.returncode, "stdout": p.stdout, "stderr": p.stderr[-3000:]}, f)
+
+
+@needs2
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a cold shell: the parent never touches the GPU, starts 2 ranks, rank 0 prints the line.
+    The cold shell is a fork-server worker (started in conftest.py before any test touched the GPU), not this process."""
+    mp.start_processes(_bench_launcher_helper, args=(str(tmp_path),), nprocs=1, join=True, start_method="forkserver")
+    r = json.load(open(tmp_path / "bench.json"))
+    assert r["returncode"] == 0, r["stderr"]
+    line = [ln for ln in r["stdout"].splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and "ulysses2" in out["config"]["parallelism"]
 

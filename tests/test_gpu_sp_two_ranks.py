@@ -45,7 +45,17 @@ def _stage_collectives_through_host():
             d.copy_(s)
         return _Done() if async_op else None
 
-    dist.all_to_all_single, dist.all_gather_into_tensor, dist.all_gather = a2a, ag_into, ag
+    real_gather = dist.gather
+
+    def gather(tensor, gather_list=None, dst=0, group=None, async_op=False):
+        host_list = [torch.empty(t.shape, dtype=t.dtype) for t in gather_list] if gather_list is not None else None
+        real_gather(tensor.detach().cpu().contiguous(), host_list, dst=dst, group=group)
+        if gather_list is not None:
+            for d, s in zip(gather_list, host_list):
+                d.copy_(s)
+        return _Done() if async_op else None
+
+    dist.all_to_all_single, dist.all_gather_into_tensor, dist.all_gather, dist.gather = a2a, ag_into, ag, gather
 
     real_batch = dist.batch_isend_irecv
 
@@ -103,7 +113,15 @@ def _worker(rank, world, port, outdir):
         cfg = syn.DiTConfig(hidden_size=512, heads_num=4, mm_double_blocks_depth=1, mm_single_blocks_depth=2)
         # (latent T,H,W), text length, valid text tokens; (3,10,16): H/2 odd -> the W axis is split
         cases = [((5, 16, 16), 32, 11), ((3, 24, 16), 32, 32), ((3, 10, 16), 16, 0)] if world == 2 else [((5, 16, 32), 32, 11)]
-        for thw, txt_len, n_valid in cases:
+        # exchange variants (long_ctx_attention.UlyssesLongContextAttention): the default (one all_to_all_single, copy3d pack) and the
+        # opt-in segmented forms - a2a staging / point-to-point pairs - with the scatter-pack store
+        variants = [dict(HV_SP_NSEG="1", HV_SP_OUT_EXCHANGE="a2a", HV_SP_SCATTER_PACK="0"),
+                    dict(HV_SP_NSEG="2", HV_SP_OUT_EXCHANGE="a2a", HV_SP_SCATTER_PACK="1"),
+                    dict(HV_SP_NSEG="2", HV_SP_OUT_EXCHANGE="p2p", HV_SP_SCATTER_PACK="1")]
+        from hunyuanvideo_efficiency_amd.long_ctx_attention import UlyssesLongContextAttention as _U
+        _U.MIN_SEG_ROWS = 16       # the toy shards are a few dozen rows: let the segmented forms actually segment
+        for ci, (thw, txt_len, n_valid) in enumerate(cases):
+            os.environ.update(variants[(ci + (2 if world == 4 else 0)) % len(variants)])
             base_model = selftest.build_model(cfg, "cuda")
             sp_model = selftest.build_model(cfg, "cuda")
             parallelize_transformer_module(sp_model, None)
@@ -167,6 +185,12 @@ def _vae_worker(rank, world, port, outdir):
         base2 = vae.decode(z2, return_dict=False)[0].clone()
         vae.enable_tile_parallel()
         assert torch.equal(vae.decode(z2, return_dict=False)[0], base2)
+        # gather-to-rank-0 mode: the root blends and holds the video, the other ranks return zeros of its shape
+        vae.enable_tile_parallel(gather="rank0")
+        out0 = vae.decode(z2, return_dict=False)[0]
+        torch.cuda.synchronize()
+        assert out0.shape == base2.shape
+        assert torch.equal(out0, base2) if rank == 0 else float(out0.abs().max()) == 0
         results[rank] = "ok"
     except Exception:  # noqa: BLE001
         import traceback
