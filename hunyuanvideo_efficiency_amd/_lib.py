@@ -50,7 +50,7 @@ SIGNATURES = {
     "hv_conv3d_causal_f16": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p],
     "hv_gn_partial_rows": [_l],
     "hv_subpixel_gn_partial_rows": [_i, _i, _i, _i],
-    "hv_groupnorm_finalize_f16": [_p, _l, _l, _i, _i, _f, _p, _p, _p, _p],
+    "hv_groupnorm_finalize_f16": [_p, _l, _l, _l, _i, _i, _f, _p, _p, _p, _p],
     "hv_groupnorm_affine_f16": [_p, _l, _l, _i, _i, _f, _p, _p, _p, _l, _p, _p],
     "hv_groupnorm_apply_f16": [_p, _l, _p, _l, _l, _i, _p, _i, _p],
     "hv_softmax_rows_f32_f16": [_p, _l, _p, _l, _i, _i, _i, _f, _i, _p],

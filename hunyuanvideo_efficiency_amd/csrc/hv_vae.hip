@@ -416,14 +416,16 @@ extern "C" int hv_groupnorm_affine_f16(const void* x, int64_t ldx, int64_t M, in
     return hv_check_launch();
 }
 
-extern "C" int hv_groupnorm_finalize_f16(const float* partial, int64_t nrow, int64_t M, int C, int groups, float eps,
-                                         const void* weight, const void* bias, float* affine_out, hipStream_t stream) {
+extern "C" int hv_groupnorm_finalize_f16(const float* partial, int64_t partial_floats, int64_t nrow, int64_t M, int C, int groups,
+                                         float eps, const void* weight, const void* bias, float* affine_out, hipStream_t stream) {
     // partial: [nrow][C][2] (sum, sum of squares) rows as written by a conv epilogue (hv_conv3d_causal_f16 `gn_partial`), followed by
     // HV_GN_FOLD_WS_FLOATS floats of workspace; M = rows of the activation the statistics cover.  The epilogue credits a pair of
     // adjacent columns to the even one: a group must hold whole pairs.
     if (!partial || !weight || !bias || !affine_out || nrow <= 0 || M <= 0 || C < 8 || (C & 7) || C > 2048 || groups <= 0 ||
         groups > 64 || (groups & (groups - 1)) || (C % groups) || ((C / groups) & 1))
         return HV_ERR_ARG;
+    // the fp64 fold scratch lives behind the partials in the caller's buffer: refuse a buffer that does not hold it
+    if (partial_floats < ((nrow * C * 2 + 1) & ~(int64_t)1) + HV_GN_FOLD_WS_FLOATS) return HV_ERR_ARG;
     int S = (int)((nrow + 1023) / 1024);                                     // >= 4 rows per thread and slab set
     if (S > HV_GN_FOLD_WS_FLOATS / (64 * 4)) S = HV_GN_FOLD_WS_FLOATS / (64 * 4);       // groups <= 64, 2 doubles = 4 floats each
     if (S < 1) S = 1;

@@ -396,12 +396,15 @@ class HYVideoDiffusionTransformer(nn.Module):
         self.img_in.run(x[0].to(torch.float32).contiguous(), ws, s_img)
         mask = text_mask if self.use_attention_mask else None
         # per-prompt cache of the refiner's timestep-independent prefix: stashed on the caller's text_states tensor OBJECT (the
-        # pipeline passes the same tensor every step; never keyed on an address) and tied to its _version and to the weights'
+        # pipeline passes the same tensor every step; never keyed on an address) and valid only for the SAME mask object at the
+        # same _version and for unmodified refiner parameters (every parameter's _version enters the key: an in-place update of
+        # any of them - optimizer step, load_state_dict - drops the cache; replacing a parameter's .data without a version bump
+        # is not detectable and needs `del text_states._hv_txt_cache`: inference-only use)
         tc = getattr(text_states, "_hv_txt_cache", None)
-        key = (text_states._version, None if mask is None else mask._version, self.txt_in.input_embedder.weight._version,
-               id(self.txt_in))
-        if tc is None or tc.get("key") != key:
-            tc = {"key": key, "text_bf16": text_states[0].to(BF16).contiguous()}
+        key = (text_states._version, None if mask is None else mask._version, id(self.txt_in),
+               tuple(p._version for p in self.txt_in.parameters()))
+        if tc is None or tc.get("key") != key or tc.get("mask") is not mask:
+            tc = {"key": key, "mask": mask, "text_bf16": text_states[0].to(BF16).contiguous()}
             try:
                 text_states._hv_txt_cache = tc
             except (AttributeError, RuntimeError):

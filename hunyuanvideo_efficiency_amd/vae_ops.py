@@ -207,7 +207,7 @@ def groupnorm_affine_from_stats(st: GNStats, weight, bias, groups: int = 32, eps
     """The same affine from statistics a conv epilogue took (conv3d_causal(..., gn_stats=True)): no pass over the activation."""
     _chk(weight, F16, "weight"), _chk(bias, F16, "bias")
     aff = torch.empty(st.C, 2, dtype=torch.float32, device=st.partial.device)
-    _lib.call("groupnorm_finalize_f16", st.partial, st.rows, st.M, st.C, groups, eps, weight, bias, aff)
+    _lib.call("groupnorm_finalize_f16", st.partial, st.partial.numel(), st.rows, st.M, st.C, groups, eps, weight, bias, aff)
     return aff
 
 

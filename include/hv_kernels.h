@@ -228,12 +228,14 @@ int hv_groupnorm_affine_f16(const void* x, int64_t ldx, int64_t M, int C, int gr
                             hipStream_t stream);
 
 /* K16 pass 2 alone: the same affine from statistics a conv epilogue already took (hv_conv3d_causal_f16 `gn_partial`):
- * partial [nrow][C][2] fp32 followed by HV_GN_FOLD_WS_FLOATS floats of workspace (the buffer a conv was given must be that much
- * longer than the conv itself requires), M = rows of the activation they cover.  Folded in fp64 in a fixed order.  The epilogue
- * credits each pair of adjacent channels to the even one, so C / groups must be even (HV_ERR_ARG otherwise). */
+ * partial [nrow][C][2] fp32 followed by HV_GN_FOLD_WS_FLOATS floats of fold workspace IN THE SAME BUFFER (the fp64 fold scratch
+ * starts at the next even float index behind the partials), M = rows of the activation they cover.  partial_floats = size of that
+ * buffer in floats: HV_ERR_ARG unless it is >= align2(nrow*C*2) + HV_GN_FOLD_WS_FLOATS (a buffer sized for the conv alone is too
+ * small and is refused, never overrun).  Folded in fp64 in a fixed order.  The epilogue credits each pair of adjacent channels
+ * to the even one, so C / groups must be even (HV_ERR_ARG otherwise). */
 #define HV_GN_FOLD_WS_FLOATS 16384
-int hv_groupnorm_finalize_f16(const float* partial, int64_t nrow, int64_t M, int C, int groups, float eps, const void* weight,
-                              const void* bias, float* affine_out, hipStream_t stream);
+int hv_groupnorm_finalize_f16(const float* partial, int64_t partial_floats, int64_t nrow, int64_t M, int C, int groups, float eps,
+                              const void* weight, const void* bias, float* affine_out, hipStream_t stream);
 
 /* K16 pass 3: y = [SiLU](x*affine[2c] + affine[2c+1]) -> fp16 (norm + nonlinearity, unet_causal_3d_blocks.py:361-363,399-405). */
 int hv_groupnorm_apply_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int C, const float* affine,
