@@ -19,48 +19,17 @@
 //     gaps before the end of the iteration.
 // Workgroups are ordered head-major so co-resident workgroups stream the same head's K/V (L2 / MALL reuse).
 // Algorithmic work: 4 * n_q * n_kv * 128 flop per head.
-#include "hv_common.hpp"
-#include "../../include/hv_kernels.h"
-#include <type_traits>
+#include "hv_attention.hpp"
+
+using namespace hv_attn;
 
 namespace {
 
-constexpr int D = 128;
 constexpr int QROWS_WAVE = 32;
 constexpr int NWAVES = 8;
 constexpr int QTILE = QROWS_WAVE * NWAVES;  // 256
-constexpr int KVT = 64;
-constexpr int KV_TILE_BYTES = KVT * D * 2;       // 16 KiB
 constexpr int BUF_BYTES = 2 * KV_TILE_BYTES;     // K + V
 constexpr int ATT_LDS = 2 * BUF_BYTES;           // 64 KiB
-
-struct AttnArgs {
-    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
-    int64_t sq, sk, sv, so;   // token strides (elements); head h lives at column h*128
-    int n_q, n_kv, n_heads, n_qtiles;
-    float scale_log2e;
-    // KV split (load balance when the grid is only a few rounds of workgroups): blockIdx.y = split s handles keys
-    // [s*split_keys, min(n_kv, (s+1)*split_keys)); partial O (unnormalised, fp32) and (m, l) go to the workspace
-    int n_splits, split_keys;
-    float* part_o;      // [n_splits][n_q][n_heads][128]
-    float* part_ml;     // [n_splits][n_q][n_heads][2]
-    int partial;        // 1: always leave the unnormalised partial (ring attention merges K/V chunks later), even unsplit
-};
-
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-
-__device__ __forceinline__ float half_swap_max(float v) {
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float half_swap_sum(float v) {
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
 
 // =====================================================================================================================
 // v5 = v4 with the per-tile barrier moved two MFMA gaps before the end of the iteration (see gap 30 in body_main): the next
@@ -454,7 +423,14 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 
 HvPerDeviceOnce g_attn_lds_once;
 
+// Which kernel the C ABI launches is a BUILD decision (no run-time selection in the product library): 0 = the 8-wave x 32-row
+// kernel of this file, 1 = the 4-wave x 64-row kernel of hv_attention_w4.hip (same AttnArgs, same 256-row workgroup tiles).
+#ifndef HV_ATTN_USE_W4
+#define HV_ATTN_USE_W4 0
+#endif
+
 int attn_launch(const AttnArgs& a, dim3 grid, hipStream_t stream) {
+    if (HV_ATTN_USE_W4) return launch_w4(a, grid, stream);
     if (hv_set_max_lds(g_attn_lds_once, (const void*)attn_fwd_kernel_v5, ATT_LDS) != HV_OK) return HV_ERR_LAUNCH;
     attn_fwd_kernel_v5<<<grid, dim3(512), ATT_LDS, stream>>>(a);
     return HV_OK;

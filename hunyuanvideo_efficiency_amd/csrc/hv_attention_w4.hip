@@ -1,0 +1,535 @@
+// Flash attention forward, bf16, head_dim 128 - the 4-wave x 64-row structure (one wave per SIMD, 512 registers per lane, the
+// accumulator half of the register file owned by inline asm through LITERAL register names).  Same arithmetic contract and the
+// same AttnArgs as the 8-wave kernel of hv_attention.hip (swapped QK^T, deferred running max in the C operand of the S chains,
+// P rounded to bf16 for P.V, unrounded row sums); what changes is who holds what:
+//
+//   workgroup = 4 waves = 256 query rows; a wave = 64 rows = two 32-row query blocks (qb).  Per 64-key tile and wave:
+//     S'^T[qb][kb] = K[kb] . Q'[qb]^T   2 x 2 chains of 8 v_mfma_f32_32x32x16_bf16           = 32 MFMAs
+//     O^T[qb][db] += V^T[db] . P^T[qb]  2 x 4 accumulator tiles x 4 k-steps of 16 keys       = 32 MFMAs
+//   and every K / V fragment read from LDS feeds BOTH query blocks: 16 ds_read_b128 + 32 ds_read_b64_tr_b16 per 64 MFMAs, half
+//   of what two 32-row waves of the 8-wave kernel read for the same work (the loop is clock/power-bound, the
+//   lever left is energy per MFMA).
+//
+// Register map (per lane; `a` registers are never named to the compiler except as clobbers, so it cannot shuttle them):
+//   a[0:127]    O^T[qb][db], tile (qb*4 + db) at a[16*(qb*4+db) : +15]            written only by the P.V MFMAs
+//   a[128:191]  Q'[qb][ks] = bf16(Q * scale * log2 e), fragment (qb*8 + ks) at a[128 + 4*(qb*8+ks) : +3]
+//   a[192:223]  K fragment ring, 8 slots of 4 (ds_read_b128 straight into the accumulator file)
+//   a[224:255]  V^T fragment ring, 8 slots of 4 (two ds_read_b64_tr_b16 each)
+//   v: S'(t) and S'(t+1) 2 x 64, -m (C operand of the S chains) 32, packed P 32, addresses / statistics ~ 30   (compiler-allocated)
+// LDS: K and V tile rings, THREE deep each (96 KiB; one workgroup per CU): the DMA of a tile never targets a buffer that is being
+// read in the same iteration, so its eight 1-KiB pieces per wave are spread over the S phase (one every fourth MFMA gap) instead
+// of sitting in a burst behind the barrier; K(t+3) and V(t+2) are issued during iteration t and retired by the COUNTED
+// `s_waitcnt vmcnt(8)` of iteration t+1's barrier.
+// Iteration t (64 MFMA gaps, one scheduling fence per gap; consumes S'(t), produces S'(t+1)):
+//   gaps  0-31  S'(t+1) chains, K fragment f = gap/2 for both query blocks | 40 of the 64 exp2 of P(t) (5 per 4 gaps), packs, row sums
+//   gaps 32-63  O += V(t).P(t), V fragment per two gaps                    | the other 24 exp2 (gaps 32-55), row max of S'(t+1)
+//   fragment f is read from LDS four fragments (eight gaps, > 256 cycles) ahead of its first MFMA, which waits with a counted
+//   lgkmcnt; barrier at gap 56 (vmcnt only: with three-deep rings no buffer read in this iteration is a DMA target before the next
+//   barrier), then the first four K fragments of the next tile.
+#include "hv_attention.hpp"
+#include "hv_agpr_clobbers.inc"
+
+using namespace hv_attn;
+
+namespace {
+
+constexpr int W4_WAVES = 4, W4_QTILE = 256, W4_NBUF = 3;
+constexpr int W4_KOFF = 0, W4_VOFF = W4_NBUF * KV_TILE_BYTES;      // LDS bytes: [K0 | K1 | K2 | V0 | V1 | V2]
+constexpr int W4_LDS = 2 * W4_NBUF * KV_TILE_BYTES;               // 96 KiB
+constexpr int A_O = 0, A_Q = 128, A_KF = 192, A_VF = 224;         // accumulator-file map (see header)
+constexpr int RING = 8;       // K and V fragment rings: 8 slots of 4 registers each
+constexpr int PF = 4;         // a fragment is read from LDS PF fragments (2 PF MFMA gaps) ahead of its first MFMA
+// LDS instructions issued between fragment f's read and its first use = the reads of fragments f+1 .. f+PF-1 (K: 1 instruction,
+// V: 2; fragments 16..31 of a tile are V, 32.. are the next tile's K)
+__host__ __device__ constexpr int frag_insts(int f) { return (f >= 16 && f < 32) ? 2 : 1; }
+// one wait per PAIR of fragments (a wave alone on its SIMD pays ~4 issue cycles per s_waitcnt even when it is satisfied): the first
+// MFMA of an even fragment f waits until f AND f+1 have landed = all but the reads of f+2 .. f+PF-1
+__host__ __device__ constexpr int wait_for(int f) { int n = 0; for (int i = 2; i < PF; ++i) n += frag_insts(f + i); return n; }
+
+// ---------------------------------------------------------------------------------------------------- asm building blocks
+// Every MFMA statement clobbers ALL of a0..a255: hipcc treats the accumulator half as overflow space for long-lived values
+// (v_accvgpr_write a22, v98 ... in the middle of the loop - into O); with the clobber on every MFMA no value of its own can stay
+// there across two gaps.  (-save-temps audit: no v_accvgpr_* outside ASMSTART/ASMEND, .vgpr_spill_count 0, no scratch.)
+// S chain: D (arch VGPRs, compiler-allocated) = K fragment (a) x Q' fragment (a) + C.  WAIT >= 0: counted lgkmcnt in front (the
+// fragment's ds_read must have landed; WAIT = LDS instructions issued after it).
+template <int KF, int QF, int WAIT>
+__device__ __forceinline__ void mfma_s_first(f32x16& s, const f32x16& c) {
+    if constexpr (WAIT >= 0)
+        asm volatile("s_waitcnt lgkmcnt(%c6)\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], a[%c4:%c5], %1"
+                     : "=&v"(s) : "v"(c), "i"(KF), "i"(KF + 3), "i"(QF), "i"(QF + 3), "i"(WAIT) : HV_CLOBBER_ALL_AGPRS);
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], a[%c4:%c5], %1"
+                     : "=&v"(s) : "v"(c), "i"(KF), "i"(KF + 3), "i"(QF), "i"(QF + 3) : HV_CLOBBER_ALL_AGPRS);
+}
+template <int KF, int QF, int WAIT>
+__device__ __forceinline__ void mfma_s_zero(f32x16& s) {
+    if constexpr (WAIT >= 0)
+        asm volatile("s_waitcnt lgkmcnt(%c5)\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0"
+                     : "=&v"(s) : "i"(KF), "i"(KF + 3), "i"(QF), "i"(QF + 3), "i"(WAIT));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=&v"(s) : "i"(KF), "i"(KF + 3), "i"(QF), "i"(QF + 3));
+}
+template <int KF, int QF, int WAIT>
+__device__ __forceinline__ void mfma_s(f32x16& s) {
+    if constexpr (WAIT >= 0)
+        asm volatile("s_waitcnt lgkmcnt(%c5)\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0"
+                     : "+v"(s) : "i"(KF), "i"(KF + 3), "i"(QF), "i"(QF + 3), "i"(WAIT) : HV_CLOBBER_ALL_AGPRS);
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "i"(KF), "i"(KF + 3), "i"(QF), "i"(QF + 3) : HV_CLOBBER_ALL_AGPRS);
+}
+// O tile (a) += V^T fragment (a) x packed P (arch VGPRs).  The P words were written by VALU instructions at least one MFMA gap
+// earlier (VALU write -> MFMA operand read wait states are met by construction; hipcc pads nothing inside or around asm).
+template <int OT, int VF, int WAIT>
+__device__ __forceinline__ void mfma_pv(const u32x4& p) {
+    if constexpr (WAIT >= 0)
+        asm volatile("s_waitcnt lgkmcnt(%c5)\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]"
+                     : : "v"(p), "i"(OT), "i"(OT + 15), "i"(VF), "i"(VF + 3), "i"(WAIT) : HV_CLOBBER_ALL_AGPRS);
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" : : "v"(p), "i"(OT), "i"(OT + 15), "i"(VF), "i"(VF + 3) : HV_CLOBBER_ALL_AGPRS);
+}
+// fragment reads straight into the accumulator file
+template <int AF, int OFF>
+__device__ __forceinline__ void lds_k(uint32_t addr) {
+    asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" : : "v"(addr), "i"(AF), "i"(AF + 3), "i"(OFF));
+}
+template <int AF, int OFF>
+__device__ __forceinline__ void lds_v(uint32_t addr) {      // keys j and j + 8 of the k-step: two transposed 8-byte reads
+    asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%c5\n\tds_read_b64_tr_b16 a[%c3:%c4], %0 offset:%c6"
+                 : : "v"(addr), "i"(AF), "i"(AF + 1), "i"(AF + 2), "i"(AF + 3), "i"(OFF), "i"(OFF + 8 * 256));
+}
+// pinned single VALU instructions (free functions: inline asm operands inside a GENERIC lambda are not captured by hipcc 7.2)
+__device__ __forceinline__ void add_pinned(float& acc, float p) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p)); }
+__device__ __forceinline__ void exp2_pinned(float& d, float x) { asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(x)); }
+__device__ __forceinline__ void pack_pinned(uint32_t& w, float lo, float hi) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi)); }
+__device__ __forceinline__ void max3_pinned(float& acc, float x, float y) { asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(x), "v"(y)); }
+template <int N>
+__device__ __forceinline__ void acc_write(uint32_t v) { asm volatile("v_accvgpr_write_b32 a%c1, %0" : : "v"(v), "i"(N)); }
+template <int N>
+__device__ __forceinline__ float acc_read() {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "i"(N));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------- schedule tables
+// exponentials of P(t) per gap: 5 per 4 gaps through the S phase (40), one per gap in gaps 32-55 (24).  The k-step kk of P.V starts
+// at gap 32 + 8 kk and needs the 16 values of (kk, both query blocks): exp index e = 16 kk + 8 qb + j is due before gap 32 + 8 kk + qb.
+__host__ __device__ constexpr int exps_before(int g) { return g <= 32 ? g + (g + 3) / 4 : (g <= 56 ? 40 + (g - 32) : 64); }
+__host__ __device__ constexpr int exps_in(int g) { return exps_before(g + 1) - exps_before(g); }
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)      // device pass only: the body names gfx950 registers and the buffer-resource type (the host pass needs the stub)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.x / a.n_qtiles;
+    const int qt = blockIdx.x % a.n_qtiles;
+    if (a.n_splits > 1) {   // this workgroup's key range
+        const int kv0 = blockIdx.y * a.split_keys;
+        a.k += (int64_t)kv0 * a.sk;
+        a.v += (int64_t)kv0 * a.sv;
+        a.n_kv = min(a.n_kv - kv0, a.split_keys);
+    }
+    const int q0 = qt * W4_QTILE + wave * 64;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+    // the whole accumulator file belongs to the asm below: this statement makes the kernel descriptor allocate a0..a255
+    asm volatile("; hv_attention_w4: a[0:255] owned by inline asm" : : : HV_CLOBBER_ALL_AGPRS);
+    // O = 0
+    static_for<0, 128>([&](auto I) { asm volatile("v_accvgpr_write_b32 a%c0, 0" : : "i"(A_O + decltype(I)::value)); });
+    // Q' = bf16(Q * scale * log2(e)) into a[128:191]
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = min(q0 + qb * 32 + lr, a.n_q - 1);
+        const bf16_t* qp = a.q + (int64_t)qrow * a.sq + head * D + lh * 8;
+        u32x4 raw[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) raw[ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+        static_for<0, 32>([&](auto I) {
+            constexpr int i = decltype(I)::value;      // word i of the query block: fragment ks = i / 4, word j = i % 4
+            const uint32_t w = raw[i >> 2][i & 3];
+            const uint32_t sc = pack_bf2(bf2f_lo(w) * a.scale_log2e, bf2f_hi(w) * a.scale_log2e);
+            if (qb == 0) acc_write<A_Q + i>(sc);
+            else acc_write<A_Q + 32 + i>(sc);
+        });
+    }
+
+    // ---- DMA addressing: wave w owns keys [16w, 16w + 16) of a tile; piece i: key = 16w + 4i + (lane >> 4), LDS chunk pos = lane & 15.
+    // buffer_load ... lds with a descriptor that starts at the tile and covers exactly its valid rows (keys past n_kv read zeros).
+    constexpr int KEYS_W = KVT / W4_WAVES, NP = KEYS_W / 4;
+    // piece i, lane: key = 16w + 4i + g (g = lane >> 4), chunk position dcp = lane & 15.  K rows are swizzled by (key & 15) = 4i ^ g,
+    // V rows by (key & 3) = g: the per-lane byte offset of piece i is that of piece 0 plus 4i rows (-> the buffer load's SCALAR
+    // offset) and, for K, XOR (i << 6) - one register per tensor instead of one per piece.
+    const char* kbase = reinterpret_cast<const char*>(a.k + head * D);
+    const char* vbase = reinterpret_cast<const char*>(a.v + head * D);
+    const int k_row_bytes = (int)a.sk * 2, v_row_bytes = (int)a.sv * 2;
+    uint32_t koff_row, koff_sw, voff0;      // (the K swizzle bits are kept apart from the row offset: a row stride need not be a multiple of 256 B)
+    {
+        const int key = KEYS_W * wave + (lane >> 4), dcp = lane & 15;
+        koff_row = (uint32_t)(key * k_row_bytes);
+        koff_sw = (uint32_t)((dcp ^ (key & 3)) << 4);
+        voff0 = (uint32_t)(key * v_row_bytes + ((dcp ^ ((key & 3) << 2)) << 4));
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wave_lds = wave_u * (KEYS_W * 256);
+    const int64_t k_tile_bytes = (int64_t)KVT * a.sk * 2, v_tile_bytes = (int64_t)KVT * a.sv * 2;
+    // rows: valid rows of the tile (64 in the steady state; fewer in a ragged last tile, whose missing keys then read as zeros)
+    auto k_rsrc = [&](const char* tile_ptr, int rows) { return __builtin_amdgcn_make_buffer_rsrc((void*)tile_ptr, 0, rows * k_row_bytes, 0x00020000); };
+    auto v_rsrc = [&](const char* tile_ptr, int rows) { return __builtin_amdgcn_make_buffer_rsrc((void*)tile_ptr, 0, rows * v_row_bytes, 0x00020000); };
+    auto dma_k_piece = [&](auto rsrc, int lds_off, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(smem + lds_off + wave_lds + i * 1024), 16, koff_row + (koff_sw ^ (uint32_t)(i << 6)), 4 * i * k_row_bytes, 0, 0);
+    };
+    auto dma_v_piece = [&](auto rsrc, int lds_off, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(smem + lds_off + wave_lds + i * 1024), 16, voff0, 4 * i * v_row_bytes, 0, 0);
+    };
+    auto tile_rows = [&](int tile) { return min(a.n_kv - tile * KVT, KVT); };
+    auto dma_k = [&](int tile, int buf) {
+        auto r = k_rsrc(kbase + tile * k_tile_bytes, tile_rows(tile));
+#pragma unroll
+        for (int i = 0; i < NP; ++i) dma_k_piece(r, W4_KOFF + buf * KV_TILE_BYTES, i);
+    };
+    auto dma_v = [&](int tile, int buf) {
+        auto r = v_rsrc(vbase + tile * v_tile_bytes, tile_rows(tile));
+#pragma unroll
+        for (int i = 0; i < NP; ++i) dma_v_piece(r, W4_VOFF + buf * KV_TILE_BYTES, i);
+    };
+
+    // ---- LDS read geometry
+    uint32_t kread0, vread;
+    {
+        // (lds0 = 0: the kernel has no static LDS, so XOR-ing swizzle bits into addresses that already contain it is exact)
+        kread0 = lds0 + W4_KOFF + lr * 256 + ((lh ^ (lr & 15)) << 4);          // kb = 1: + 32 * 256 (key & 15 unchanged)
+        const int vq = (lane & 15) >> 2, vp = lane & 3, vG = lane >> 4;
+        const int key = 4 * (vG >> 1) + vq;
+        const int chunk16 = ((vG & 1) * 16 + 4 * vp) >> 3;
+        vread = lds0 + W4_VOFF + key * 256 + ((chunk16 ^ ((key & 3) << 2)) << 4) + (vp & 1) * 8;
+    }
+    // per-tile fragment addresses: K fragment ks at (vk0 ^ (ks << 5)), vk0 = kread0 + K buffer (one XOR per read, no address table);
+    // V fragment db at vv[db] = (vread + V buffer) ^ (db << 6)
+    uint32_t vk0, vv[4];
+    auto set_vk = [&](int buf_bytes) { vk0 = kread0 + buf_bytes; };
+    auto set_vv = [&](int buf_bytes) {
+        const uint32_t b = vread + buf_bytes;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) vv[db] = b ^ (db << 6);
+    };
+
+    int rb0 = 0, rb1 = KV_TILE_BYTES, rb2 = 2 * KV_TILE_BYTES;      // LDS byte offsets of the buffers of tiles t, t+1, t+2 (rotated per iteration)
+    // ---- softmax state per query block
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    f32x16 negm[2];
+    constexpr float THR = 8.0f;
+    const int ntiles = (a.n_kv + KVT - 1) / KVT;
+
+    // tail mask (last tile) + row max of a score tile pair (relative to m_run)
+    auto tile_max = [&](f32x16 (&S)[2][2], int t, bool last, float (&mx)[2]) {
+        if (last && (a.n_kv & (KVT - 1))) {
+            const int kbase_i = t * KVT + 4 * lh;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kbase_i + kb * 32 + (r & 3) + 8 * (r >> 2);
+                        if (key >= a.n_kv) S[qb][kb][r] = -INFINITY;
+                    }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float m = S[qb][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, S[qb][0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, S[qb][1][r]);
+            mx[qb] = half_swap_max(m);
+        }
+    };
+    // rare: some row of this tile exceeds its running max by more than THR -> move every row's max of that query block, rescale its
+    // sums, this tile's scores (already relative to the old max), the C operand of the next S chains and its O tiles (accumulator file:
+    // read - multiply - write; the P.V MFMAs that last wrote them are at least one fenced gap + the nops below behind)
+    auto raise_max = [&](f32x16 (&Sc)[2][2], const float (&mx)[2]) {
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        static_for<0, 2>([&](auto QB) {
+            constexpr int qb = decltype(QB)::value;
+            if (__any(mx[qb] > THR)) {
+                const float d = fmaxf(mx[qb], 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                l_run[qb] *= alpha;
+                m_run[qb] += d;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Sc[qb][kb][r] -= d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[qb][r] = -m_run[qb];
+                static_for<0, 64>([&](auto I) {
+                    constexpr int n = A_O + 64 * qb + decltype(I)::value;
+                    float o = acc_read<n>();
+                    o *= alpha;
+                    acc_write<n>(__float_as_uint(o));
+                });
+                asm volatile("s_nop 3" ::: "memory");
+            }
+        });
+        asm volatile("" : "+v"(negm[0]), "+v"(negm[1]));
+    };
+
+    // ------------------------------------------------------------------------------------------------ steady-state iteration
+    // consumes Sc = S'(t) with row maxima mx_c, produces Sn = S'(t+1) and mx_n.  On entry: fragments 0, 1 of K(t+1) are in flight
+    // into K slots 0, 1 (issued at gaps 60, 62 of the previous iteration / the prologue), vk[] points at K(t+1)'s buffer,
+    // K(t+2) and V(t+1) have landed or are in flight (retired by this iteration's barrier).
+    // FULL: t + 3 < ntiles (both DMAs of this iteration exist, the tile it produces is not the last): no guards, counted vmcnt.
+    auto body = [&](f32x16 (&Sc)[2][2], f32x16 (&Sn)[2][2], int t, const float (&mx_c)[2], float (&mx_n)[2], auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        if (__any(mx_c[0] > THR || mx_c[1] > THR)) raise_max(Sc, mx_c);
+        // ring positions as LDS byte offsets, rotated by the caller (no division): rb0 = buffer of tile t (V(t); K(t+3) is DMA'd
+        // over K(t)), rb2 = buffer of tile t+2 (K(t+2): next S phase; V(t+2) is DMA'd over V(t-1))
+        const bool do_k = FULL || (t + 3 < ntiles), do_v = FULL || (t + 2 < ntiles);
+        u32x4 pw[2][4];                       // packed P: [qb][k-step]
+        float ex[64];                         // this tile's exponentials (compile-time indices: each lives for about two gaps)
+        float mxa[2] = {-INFINITY, -INFINITY};
+        // descriptors of this iteration's DMAs (scalar arithmetic; a tile past the end is clamped - its pieces are not issued)
+        const auto krs = k_rsrc(kbase + (FULL ? t + 3 : min(t + 3, ntiles - 1)) * k_tile_bytes, FULL ? KVT : tile_rows(min(t + 3, ntiles - 1)));
+        const auto vrs = v_rsrc(vbase + (FULL ? t + 2 : min(t + 2, ntiles - 1)) * v_tile_bytes, FULL ? KVT : tile_rows(min(t + 2, ntiles - 1)));
+        auto add_e = [&](auto Ec) {
+            constexpr int e = decltype(Ec)::value, qb = (e >> 3) & 1;
+            add_pinned(l_run[qb], ex[e]);
+        };
+        auto exp_e = [&](auto Ec) {
+            constexpr int e = decltype(Ec)::value, kk = e >> 4, qb = (e >> 3) & 1, j = e & 7;
+            // pinned too: the stream of a gap is then exactly its source order - MFMA, fragment reads, the adds / packs of the PREVIOUS
+            // gap's exponentials, this gap's exponentials, row max - and every transcendental result has the next gap's MFMA between
+            // it and its first reader (trans -> VALU forwarding needs one independent instruction; hipcc pads nothing around asm)
+            exp2_pinned(ex[e], Sc[qb][kk >> 1][8 * (kk & 1) + j]);
+        };
+        // the pack of a pair rides one gap behind its second exponential, as a pinned instruction (a compiler-placed v_cvt_pk right
+        // behind the v_exp_f32 it reads costs an s_nop: hipcc does not count the asm statements in between as wait states)
+        auto pack_e = [&](auto Ec) {
+            constexpr int e = decltype(Ec)::value, kk = e >> 4, qb = (e >> 3) & 1, j = e & 7;
+            if constexpr (j & 1) {
+                uint32_t w;
+                pack_pinned(w, ex[e - 1], ex[e]);
+                pw[qb][kk][j >> 1] = w;
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 64>([&](auto Gc) {
+            constexpr int G = decltype(Gc)::value;
+            // ---- the gap's MFMA
+            if constexpr (G < 32) {
+                constexpr int kb = G >> 4, ks = (G & 15) >> 1, qb = G & 1, f = G >> 1;
+                constexpr int KF = A_KF + 4 * (f % RING), QF = A_Q + 4 * (qb * 8 + ks);
+                constexpr int WAIT = (qb == 0 && (f & 1) == 0) ? wait_for(f) : -1;
+                if constexpr (ks == 0) mfma_s_first<KF, QF, WAIT>(Sn[qb][kb], negm[qb]);
+                else mfma_s<KF, QF, WAIT>(Sn[qb][kb]);
+            } else {
+                constexpr int j = G - 32, kk = j >> 3, db = (j & 7) >> 1, qb = j & 1, f = 16 + (j >> 1);
+                constexpr int VF = A_VF + 4 * (f % RING), OT = A_O + 16 * (qb * 4 + db);
+                constexpr int WAIT = (qb == 0 && (f & 1) == 0) ? wait_for(f) : -1;
+                mfma_pv<OT, VF, WAIT>(pw[qb][kk]);
+            }
+            // ---- barrier (gap 56): K(t+2) / V(t+1) - this wave's pieces by the counted vmcnt, everyone's by the barrier - have landed
+            // before the first K(t+2) fragment read below.  No lgkmcnt: the buffers read in this iteration (K(t+1), V(t)) become DMA
+            // targets only in iteration t+1 (K(t+4) at its gap 3, V(t+3) at its gap 19), behind this barrier and hundreds of cycles
+            // after the last read of them was issued (gap 54).
+            if constexpr (G == 2 * (32 - PF)) {
+                if constexpr (FULL) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            // ---- fragment reads, PF fragments ahead (even gaps)
+            if constexpr ((G & 1) == 0) {
+                constexpr int f = (G >> 1) + PF;
+                if constexpr (f < 16) {
+                    lds_k<A_KF + 4 * (f % RING), (f >> 3) * 32 * 256>(vk0 ^ ((f & 7) << 5));
+                } else if constexpr (f < 32) {
+                    constexpr int j2 = f - 16, kk = j2 >> 2, db = j2 & 3;
+                    lds_v<A_VF + 4 * (f % RING), kk * 16 * 256>(vv[db]);
+                } else {
+                    // K(t+2) fragments 0 .. PF-1 (vk0 re-pointed at gap 44); the reads are issued even when there is no tile t+2 (stale but
+                    // mapped LDS, never consumed) so that the counted waits above see the same instruction stream in every iteration
+                    lds_k<A_KF + 4 * (f % RING), 0>(vk0 ^ ((f & 7) << 5));
+                }
+            }
+            // ---- per-tile address registers: V(t) before its first read (gap 28), K(t+2) after the last K(t+1) read (gap 26)
+            if constexpr (G == 12) set_vv(rb0);
+            if constexpr (G == 44) set_vk(rb2);
+            // ---- row sums: one pinned v_add_f32 per value, one gap after its v_exp_f32
+            if constexpr (G >= 1) {
+                constexpr int e0 = exps_before(G - 1), n = exps_in(G - 1);
+                if constexpr (n >= 1) { add_e(std::integral_constant<int, e0>{}); pack_e(std::integral_constant<int, e0>{}); }
+                if constexpr (n >= 2) { add_e(std::integral_constant<int, e0 + 1>{}); pack_e(std::integral_constant<int, e0 + 1>{}); }
+            }
+            // ---- exponentials + packs of P(t): e = 16 kk + 8 qb + j -> S'(t)[qb][kb = kk >> 1][8 (kk & 1) + j]
+            {
+                constexpr int e0 = exps_before(G), n = exps_in(G);
+                if constexpr (n >= 1) exp_e(std::integral_constant<int, e0>{});
+                if constexpr (n >= 2) exp_e(std::integral_constant<int, e0 + 1>{});
+            }
+            // ---- row max of S'(t+1), two values per gap and chain-complete order (gaps 32-63); the masked variant runs after the gaps
+            if constexpr (G >= 32 && FULL) {
+                constexpr int mi = G - 32, c = mi >> 3, qb = c & 1, kb = c >> 1, r = 2 * (mi & 7);
+                max3_pinned(mxa[qb], Sn[qb][kb][r], Sn[qb][kb][r + 1]);
+            }
+            // ---- DMA: K(t+3) pieces at gaps 3, 7, 11, 15, V(t+2) pieces at gaps 19, 23, 27, 31
+            if constexpr (G < 32 && (G & 3) == 3) {
+                constexpr int i = (G >> 2) & 3;
+                if constexpr (G < 16) {
+                    if (do_k) dma_k_piece(krs, W4_KOFF + rb0, i);
+                } else {
+                    if (do_v) dma_v_piece(vrs, W4_VOFF + rb2, i);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // the last gap's exponential-less tail: nothing is pending (exps end at gap 55, their adds at 56)
+        if constexpr (FULL) {
+            mx_n[0] = half_swap_max(mxa[0]);
+            mx_n[1] = half_swap_max(mxa[1]);
+        } else {
+            tile_max(Sn, t + 1, t + 2 == ntiles, mx_n);
+        }
+        // rotate the ring: tile t+1's buffer becomes "rb0"
+        const int r = rb0;
+        rb0 = rb1;
+        rb1 = rb2;
+        rb2 = r;
+    };
+
+    // ------------------------------------------------------------------------------------------------ prologue
+    f32x16 sA[2][2], sB[2][2];
+    dma_k(0, 0);
+    dma_v(0, 0);
+    if (ntiles > 1) { dma_k(1, 1); dma_v(1, 1); }
+    if (ntiles > 2) dma_k(2, 2);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");       // K(0..2) / V(0..1) landed for everyone (a barrier alone does not wait for LDS-DMA)
+    set_vk(0);
+    // S(0): one fragment at a time (prologue, once per ~1900 tiles)
+    static_for<0, 16>([&](auto F) {
+        constexpr int f = decltype(F)::value, kb = f >> 3, ks = f & 7, KF = A_KF + 4 * (f % RING);
+        lds_k<KF, kb * 32 * 256>(vk0 ^ (ks << 5));
+        static_for<0, 2>([&](auto QB) {
+            constexpr int qb = decltype(QB)::value, QF = A_Q + 4 * (qb * 8 + ks);
+            if constexpr (ks == 0) mfma_s_zero<KF, QF, (qb == 0 ? 0 : -1)>(sA[qb][kb]);
+            else mfma_s<KF, QF, (qb == 0 ? 0 : -1)>(sA[qb][kb]);
+        });
+    });
+    // MFMA D -> VALU readers; and every wave is done reading K(0) before iteration 0 starts the DMA of K(3) over it
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(sA[0][0]), "+v"(sA[0][1]), "+v"(sA[1][0]), "+v"(sA[1][1]) : : "memory");
+    // tile 0 fixes the initial max exactly: m_run = rowmax(S(0)), S'(0) = S(0) - m_run (the only explicit subtraction)
+    float mxA[2], mxB[2] = {0.f, 0.f};
+    tile_max(sA, 0, ntiles == 1, mxA);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        m_run[qb] = mxA[qb];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sA[qb][kb][r] -= m_run[qb];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[qb][r] = -m_run[qb];
+        mxA[qb] = 0.f;
+    }
+    asm volatile("" : "+v"(negm[0]), "+v"(negm[1]));
+    // entry state of iteration 0: vk -> K(1), its fragments 0, 1 in flight; K(2), V(1) landed (prologue wait)
+    if (ntiles > 1) {
+        set_vk(KV_TILE_BYTES);
+        static_for<0, PF>([&](auto F) { lds_k<A_KF + 4 * decltype(F)::value, 0>(vk0 ^ (uint32_t)(decltype(F)::value << 5)); });
+    }
+    int t = 0;
+    for (; t + 4 < ntiles; t += 2) {        // both calls FULL: K((t+1)+3) exists
+        body(sA, sB, t, mxA, mxB, std::true_type{});
+        body(sB, sA, t + 1, mxB, mxA, std::true_type{});
+    }
+    for (; t + 1 < ntiles; ++t) {           // the 0-5 iterations left before the final tile: guarded DMA, masked row max, full drains
+        body(sA, sB, t, mxA, mxB, std::false_type{});
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sA[qb][kb] = sB[qb][kb];
+            mxA[qb] = mxB[qb];
+        }
+    }
+    // ------------------------------------------------------------------------------------------------ last tile: P(t) and O += V.P only
+    {
+        if (__any(mxA[0] > THR || mxA[1] > THR)) raise_max(sA, mxA);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        set_vv(rb0);
+        u32x4 pw[2][4];
+        float ls[2] = {0.f, 0.f};
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(sA[qb][kk >> 1][8 * (kk & 1) + j]);
+                    const float p1 = __builtin_amdgcn_exp2f(sA[qb][kk >> 1][8 * (kk & 1) + j + 1]);
+                    ls[qb] += p0;
+                    ls[qb] += p1;
+                    pw[qb][kk][j >> 1] = pack_bf2(p0, p1);
+                }
+        asm volatile("s_nop 1" : "+v"(pw[0][0]), "+v"(pw[0][1]), "+v"(pw[0][2]), "+v"(pw[0][3]), "+v"(pw[1][0]), "+v"(pw[1][1]), "+v"(pw[1][2]),
+                     "+v"(pw[1][3]));
+        static_for<0, 16>([&](auto F) {
+            constexpr int f = decltype(F)::value, kk = f >> 2, db = f & 3, VF = A_VF + 4 * (f % RING);
+            lds_v<VF, kk * 16 * 256>(vv[db]);
+            static_for<0, 2>([&](auto QB) {
+                constexpr int qb = decltype(QB)::value;
+                mfma_pv<A_O + 16 * (qb * 4 + db), VF, (qb == 0 ? 0 : -1)>(pw[qb][kk]);
+            });
+        });
+        l_run[0] += ls[0];
+        l_run[1] += ls[1];
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");      // last P.V MFMAs -> accumulator reads below
+
+    // ------------------------------------------------------------------------------------------------ epilogue
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float o[64];
+        if (qb == 0) static_for<0, 64>([&](auto I) { o[decltype(I)::value] = acc_read<A_O + decltype(I)::value>(); });
+        else static_for<0, 64>([&](auto I) { o[decltype(I)::value] = acc_read<A_O + 64 + decltype(I)::value>(); });
+        const float l_tot = half_swap_sum(l_run[qb]);
+        const int qrow = q0 + qb * 32 + lr;
+        if (a.n_splits > 1 || a.partial) {   // partial result: O^T unnormalised (fp32) + (m, l); merged by attn_combine_kernel
+            if (qrow < a.n_q) {
+                const int64_t rowi = ((int64_t)blockIdx.y * a.n_q + qrow) * a.n_heads + head;
+                float* po = a.part_o + rowi * D + 4 * lh;
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(po + db * 32 + g * 8) =
+                            make_float4(o[db * 16 + 4 * g], o[db * 16 + 4 * g + 1], o[db * 16 + 4 * g + 2], o[db * 16 + 4 * g + 3]);
+                if (lh == 0) {
+                    a.part_ml[rowi * 2] = m_run[qb];
+                    a.part_ml[rowi * 2 + 1] = l_tot;
+                }
+            }
+        } else if (qrow < a.n_q) {
+            const float inv = 1.0f / l_tot;
+            bf16_t* op = a.o + (int64_t)qrow * a.so + head * D + 4 * lh;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 w;
+                    w[0] = pack_bf2(o[db * 16 + 4 * g] * inv, o[db * 16 + 4 * g + 1] * inv);
+                    w[1] = pack_bf2(o[db * 16 + 4 * g + 2] * inv, o[db * 16 + 4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2*>(op + db * 32 + g * 8) = w;
+                }
+        }
+    }
+#endif
+}
+
+HvPerDeviceOnce g_w4_lds_once;
+
+}  // namespace
+
+int hv_attn::launch_w4(const AttnArgs& a, dim3 grid, hipStream_t stream) {
+    if (hv_set_max_lds(g_w4_lds_once, (const void*)attn_fwd_kernel_w4, W4_LDS) != HV_OK) return HV_ERR_LAUNCH;
+    attn_fwd_kernel_w4<<<grid, dim3(256), W4_LDS, stream>>>(a);
+    return HV_OK;
+}
