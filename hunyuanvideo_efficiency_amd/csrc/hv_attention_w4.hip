@@ -111,6 +111,16 @@ __device__ __forceinline__ float acc_read() {
     return v;
 }
 
+// the steady-state iteration as ONE asm statement with literal registers (tools/gen_attn_w4_asm.py)
+#ifdef HV_W4_STAMPS      // diagnostic build (tools/attn_variants): the generated iteration with s_memtime stamps around the barrier's waits
+#include "hv_attention_w4_loop_stamps.inc"
+__device__ unsigned g_w4_dbg[8];
+#define HV_W4_DBG_ARGS , dbg_vm, dbg_bar, dbg_pre, dbg_p1, dbg_p2, dbg_p3
+#else
+#include "hv_attention_w4_loop.inc"
+#define HV_W4_DBG_ARGS
+#endif
+
 // ---------------------------------------------------------------------------------------------------- schedule tables
 // exponentials of P(t) per gap: 5 per 4 gaps through the S phase (40), one per gap in gaps 32-55 (24).  The k-step kk of P.V starts
 // at gap 32 + 8 kk and needs the 16 values of (kk, both query blocks): exp index e = 16 kk + 8 qb + j is due before gap 32 + 8 kk + qb.
@@ -170,6 +180,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
         koff_sw = (uint32_t)((dcp ^ (key & 3)) << 4);
         voff0 = (uint32_t)(key * v_row_bytes + ((dcp ^ ((key & 3) << 2)) << 4));
     }
+    u32x4 koff4, voff4;      // the asm iteration's per-piece voffsets (row step folded in: its buffer loads use soffset 0)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        koff4[i] = koff_row + (koff_sw ^ (uint32_t)(i << 6)) + (uint32_t)(4 * i * k_row_bytes);
+        voff4[i] = voff0 + (uint32_t)(4 * i * v_row_bytes);
+    }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wave_lds = wave_u * (KEYS_W * 256);
     const int64_t k_tile_bytes = (int64_t)KVT * a.sk * 2, v_tile_bytes = (int64_t)KVT * a.sv * 2;
@@ -217,12 +233,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     int rb0 = 0, rb1 = KV_TILE_BYTES, rb2 = 2 * KV_TILE_BYTES;      // LDS byte offsets of the buffers of tiles t, t+1, t+2 (rotated per iteration)
     // ---- softmax state per query block
     float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    float l2_run[2] = {0.f, 0.f};      // second partial row sums of the asm iteration (odd exponentials), folded into l_run at a rescale and at the end
     f32x16 negm[2];
     constexpr float THR = 8.0f;
     const int ntiles = (a.n_kv + KVT - 1) / KVT;
 
     // tail mask (last tile) + row max of a score tile pair (relative to m_run)
-    auto tile_max = [&](f32x16 (&S)[2][2], int t, bool last, float (&mx)[2]) {
+    auto tile_max = [&](f32x16 (&S)[2][2], int t, bool last, float (&mx)[2]) __attribute__((always_inline)) {
         if (last && (a.n_kv & (KVT - 1))) {
             const int kbase_i = t * KVT + 4 * lh;
 #pragma unroll
@@ -248,14 +265,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     // rare: some row of this tile exceeds its running max by more than THR -> move every row's max of that query block, rescale its
     // sums, this tile's scores (already relative to the old max), the C operand of the next S chains and its O tiles (accumulator file:
     // read - multiply - write; the P.V MFMAs that last wrote them are at least one fenced gap + the nops below behind)
-    auto raise_max = [&](f32x16 (&Sc)[2][2], const float (&mx)[2]) {
+    auto raise_max = [&](f32x16 (&Sc)[2][2], const float (&mx)[2]) __attribute__((always_inline)) {
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
         static_for<0, 2>([&](auto QB) {
             constexpr int qb = decltype(QB)::value;
             if (__any(mx[qb] > THR)) {
-                const float d = fmaxf(mx[qb], 0.f);
+                const float d = fmaxf(half_swap_max(mx[qb]), 0.f);      // (mx may be lane-local: the two lanes of a query agree after the swap)
                 const float alpha = __builtin_amdgcn_exp2f(-d);
-                l_run[qb] *= alpha;
+                l_run[qb] = (l_run[qb] + l2_run[qb]) * alpha;
+                l2_run[qb] = 0.f;
                 m_run[qb] += d;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     // into K slots 0, 1 (issued at gaps 60, 62 of the previous iteration / the prologue), vk[] points at K(t+1)'s buffer,
     // K(t+2) and V(t+1) have landed or are in flight (retired by this iteration's barrier).
     // FULL: t + 3 < ntiles (both DMAs of this iteration exist, the tile it produces is not the last): no guards, counted vmcnt.
-    auto body = [&](f32x16 (&Sc)[2][2], f32x16 (&Sn)[2][2], int t, const float (&mx_c)[2], float (&mx_n)[2], auto full_c) {
+    auto body = [&](f32x16 (&Sc)[2][2], f32x16 (&Sn)[2][2], int t, const float (&mx_c)[2], float (&mx_n)[2], auto full_c) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;
         if (__any(mx_c[0] > THR || mx_c[1] > THR)) raise_max(Sc, mx_c);
         // ring positions as LDS byte offsets, rotated by the caller (no division): rb0 = buffer of tile t (V(t); K(t+3) is DMA'd
@@ -437,10 +455,50 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
         static_for<0, PF>([&](auto F) { lds_k<A_KF + 4 * decltype(F)::value, 0>(vk0 ^ (uint32_t)(decltype(F)::value << 5)); });
     }
     int t = 0;
-    for (; t + 4 < ntiles; t += 2) {        // both calls FULL: K((t+1)+3) exists
-        body(sA, sB, t, mxA, mxB, std::true_type{});
-        body(sB, sA, t + 1, mxB, mxA, std::true_type{});
+    // steady state: the generated single-statement iterations (every register literal); t + 3 < ntiles for both of a pair
+    auto desc = [&](const char* p, int row_bytes) __attribute__((always_inline)) {      // buffer descriptor of one whole tile (what make_buffer_rsrc builds), in SGPRs
+        const uint64_t a64 = (uint64_t)(uintptr_t)p;
+        u32x4 d;
+        d[0] = (uint32_t)a64;
+        d[1] = (uint32_t)(a64 >> 32) & 0xffffu;
+        d[2] = (uint32_t)(KVT * row_bytes);
+        d[3] = 0x00020000u;
+        return d;
+    };
+#ifdef HV_W4_STAMPS
+    uint32_t dbg_vm = 0, dbg_bar = 0, dbg_pre = 0, dbg_p1 = 0, dbg_p2 = 0, dbg_p3 = 0;
+    const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    auto iter_full = [&](auto ab_c, int tt) __attribute__((always_inline)) {
+        constexpr bool AB = decltype(ab_c)::value;
+        float (&mc)[2] = AB ? mxA : mxB;
+        float (&mn)[2] = AB ? mxB : mxA;
+        if (__any(mc[0] > THR || mc[1] > THR)) {
+            if (AB) raise_max(sA, mc);
+            else raise_max(sB, mc);
+        }
+        const u32x4 krs = desc(kbase + (tt + 3) * k_tile_bytes, k_row_bytes), vrs = desc(vbase + (tt + 2) * v_tile_bytes, v_row_bytes);
+        const uint32_t kdst = lds0 + W4_KOFF + rb0 + wave_lds, vdst = lds0 + W4_VOFF + rb2 + wave_lds;
+        if (AB) w4_iter_ab(sA, sB, negm, l_run, l2_run, mn, vk0, kread0, vread, koff4, voff4, krs, vrs, kdst, vdst, (uint32_t)rb0, (uint32_t)rb2 HV_W4_DBG_ARGS);
+        else w4_iter_ba(sA, sB, negm, l_run, l2_run, mn, vk0, kread0, vread, koff4, voff4, krs, vrs, kdst, vdst, (uint32_t)rb0, (uint32_t)rb2 HV_W4_DBG_ARGS);
+        const int r = rb0;
+        rb0 = rb1;
+        rb1 = rb2;
+        rb2 = r;
+    };
+    for (; t + 4 < ntiles; t += 2) {
+        iter_full(std::true_type{}, t);
+        iter_full(std::false_type{}, t + 1);
     }
+#ifdef HV_W4_STAMPS
+    if (blockIdx.x == 300 && wave_u == 1 && lane == 0) {       // a mid-launch workgroup (every CU busy), one wave
+        const uint64_t dbg_t1 = __builtin_amdgcn_s_memtime();
+        g_w4_dbg[0] = dbg_vm; g_w4_dbg[1] = dbg_bar; g_w4_dbg[2] = dbg_pre; g_w4_dbg[3] = (unsigned)(dbg_t1 - dbg_t0); g_w4_dbg[4] = (unsigned)t; g_w4_dbg[5] = dbg_p1; g_w4_dbg[6] = dbg_p2; g_w4_dbg[7] = dbg_p3;
+    }
+#endif
+    l_run[0] += l2_run[0];
+    l_run[1] += l2_run[1];
+    l2_run[0] = l2_run[1] = 0.f;
     for (; t + 1 < ntiles; ++t) {           // the 0-5 iterations left before the final tile: guarded DMA, masked row max, full drains
         body(sA, sB, t, mxA, mxB, std::false_type{});
 #pragma unroll
@@ -527,6 +585,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
 HvPerDeviceOnce g_w4_lds_once;
 
 }  // namespace
+
+#ifdef HV_W4_STAMPS
+extern "C" int hv_attn_w4_debug_read(unsigned* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_dbg), sizeof(unsigned) * 8) == hipSuccess ? 0 : -1; }
+#endif
 
 int hv_attn::launch_w4(const AttnArgs& a, dim3 grid, hipStream_t stream) {
     if (hv_set_max_lds(g_w4_lds_once, (const void*)attn_fwd_kernel_w4, W4_LDS) != HV_OK) return HV_ERR_LAUNCH;

@@ -72,3 +72,68 @@ def test_generated_torch_ops_source_is_up_to_date():
     g = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(g)
     assert open(g.OUT).read() == g.gen(), "include/hv_kernels.h changed: run python tools/gen_torch_ops.py"
+
+
+def test_generated_attention_iteration_is_up_to_date_and_consistent():
+    """hv_attention_w4_loop.inc (the steady-state attention iteration as one asm statement) == what tools/gen_attn_w4_asm.py emits,
+    and the schedule tables it is built from are self-consistent: every exponential is issued exactly once, every packed P word is
+    written before the P.V MFMA that reads it (with at least one gap in between: VALU write -> MFMA operand wait states), every
+    fragment read precedes its first MFMA by PF fragments and the counted lgkmcnt of that MFMA equals the LDS instructions issued
+    in between."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("gen_attn_w4_asm", os.path.join(ROOT, "tools", "gen_attn_w4_asm.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    assert not g.STAMPS and not g.ABL
+    assert open(g.OUT).read() == g.main(), "run python tools/gen_attn_w4_asm.py"
+    body = g.gen_iter(0, 64)
+    gaps, cur = [], None
+    for ln in body:
+        if ln.startswith("; ---- gap"):
+            cur = []
+            gaps.append(cur)
+        else:
+            cur.append(ln)
+    assert len(gaps) == 64 and all(sum("v_mfma" in x for x in gp) == 1 for gp in gaps)
+    exps = [ln for gp in gaps for ln in gp if ln.startswith("v_exp_f32")]
+    assert len(exps) == 64 and len({ln.split(",")[1].strip() for ln in exps}) == 64            # every S'(t) register exactly once
+    assert sum(ln.startswith("v_add_f32") for gp in gaps for ln in gp) == 64
+    assert sum(ln.startswith("v_cvt_pk") for gp in gaps for ln in gp) == 32
+    assert sum(ln.startswith("buffer_load") for gp in gaps for ln in gp) == 8
+    # packed P words: written (v_cvt_pk dest) in a gap strictly before the MFMA that reads their tuple
+    written = {}
+    for gi, gp in enumerate(gaps):
+        for ln in gp:
+            if ln.startswith("v_cvt_pk"):
+                written[int(re.match(r"v_cvt_pk_bf16_f32 v(\d+),", ln).group(1))] = gi
+    for gi, gp in enumerate(gaps[32:], start=32):
+        m = re.search(r"v_mfma_f32_32x32x16_bf16 a\[\d+:\d+\], a\[\d+:\d+\], v\[(\d+):(\d+)\]", [x for x in gp if "v_mfma" in x][0])
+        lo, hi = int(m.group(1)), int(m.group(2))
+        assert all(written[r] < gi for r in range(lo, hi + 1)), (gi, lo, hi)
+    # fragment reads / counted waits: replay the LDS queue
+    issued = []          # (fragment slot register, gap) in issue order
+    for gi, gp in enumerate(gaps):
+        for ln in gp:
+            if ln.startswith("ds_read"):
+                issued.append((int(re.search(r"a\[(\d+):", ln).group(1)), gi))
+    assert len(issued) == 16 + 32
+    # steady state: the stream of the previous iteration precedes this one; a wait lgkmcnt(N) at gap g leaves the N youngest of the reads
+    # issued before it outstanding - the fragment registers of this gap's MFMA (and of the next fragment) must not be among them
+    prev = [(r, gi - 64) for r, gi in issued]
+    for gi, gp in enumerate(gaps):
+        w = [x for x in gp if x.startswith("s_waitcnt lgkmcnt")]
+        if not w:
+            continue
+        n = int(re.search(r"lgkmcnt\((\d+)\)", w[0]).group(1))
+        before = [x for x in prev + issued if x[1] < gi]
+        pending = {r for r, _ in before[len(before) - n:]} if n else set()
+        mf = [x for x in gp if "v_mfma" in x][0]
+        frag = int(re.findall(r"a\[(\d+):\d+\]", mf)[1 if gi >= 32 else 0])
+        assert frag >= 192 and frag not in pending and not any(r in (frag, frag + 2) for r in pending), (gi, n, frag, pending)
+        # one wait per PAIR of fragments: the MFMAs two gaps later (next fragment) issue without a wait of their own
+        if gi + 2 < 64:
+            mf2 = [x for x in gaps[gi + 2] if "v_mfma" in x][0]
+            assert not [x for x in gaps[gi + 2] if x.startswith("s_waitcnt lgkmcnt")]
+            frag2 = int(re.findall(r"a\[(\d+):\d+\]", mf2)[1 if gi + 2 >= 32 else 0])
+            assert not any(r in (frag2, frag2 + 2) for r in pending), (gi, n, frag2, pending)

@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Generate hunyuanvideo_efficiency_amd/csrc/hv_attention_w4_loop.inc: the steady-state iteration of the 4-wave x 64-row attention
+kernel (hv_attention_w4.hip) as ONE inline-asm statement with every register named literally.
+
+Why one statement: hipcc pads an `s_nop` in front of every instruction that reads a VGPR the previous asm statement wrote (it
+does not count the instructions inside asm as wait states), so a loop built from one asm statement per instruction carries ~1.5
+s_nop per MFMA gap - and a wave that is alone on its SIMD pays ~4 issue cycles for each (MI355X_MICROARCH.md, 'vector-instruction
+ISSUE cost').  Inside one statement nothing is padded; the wait states below are met by placement and stated where they matter.
+
+Register map (arch VGPRs pinned by "{v[..]}" constraints, accumulator registers owned by literal names):
+  v[0:63]   S_A  tile (qb, kb) at 16 (2 qb + kb)        v[64:127] S_B           (roles swap every iteration: AB / BA statements)
+  v[128:159] -m, the C operand of the S chains (qb 0 | 1)
+  v[160:191] packed P: (qb, k-step kk) at 160 + 4 (4 qb + kk)
+  v[192:199] ring of the last 8 exponentials     v200 v201 row sums l[qb]     v202 v203 row max of S'(t+1) [qb] (lane-local)
+  v204 K fragment base of the tile being read    v205 v220 XOR temporaries     v[206:209] V fragment bases (db 0..3)
+  v210 kread0   v211 vread   v[212:215] K DMA offsets (piece 0..3)   v[216:219] V DMA offsets
+  a[0:127] O   a[128:191] Q'   a[192:223] K fragment ring (8 x 4)   a[224:255] V fragment ring (8 x 4)
+Schedule per iteration t (64 MFMA gaps): see hv_attention_w4.hip header; the tables here are the single source of it.
+"""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.environ.get("HV_W4_INC_OUT") or os.path.join(ROOT, "hunyuanvideo_efficiency_amd", "csrc", "hv_attention_w4_loop.inc")
+
+A_O, A_Q, A_KF, A_VF = 0, 128, 192, 224
+RING, PF = 8, 4
+LAG = int(os.environ.get("HV_W4_LAG", "1"))       # gaps between a v_exp_f32 and the pack / row-sum add that read it
+EXR = 12                                          # ring of the last exponentials (>= 2 per gap x (LAG + 1) + the pair partner)
+V_NEGM, V_PW, V_EX, V_L, V_MX, V_VK0, V_T0, V_T1, V_VV, V_KREAD0, V_VREAD, V_KOFF, V_VOFF = 128, 160, 222, 200, 202, 204, 205, 220, 206, 210, 211, 212, 216
+V_L2 = 234      # second partial row sum per query block (v234, v235): consecutive adds never hit the same accumulator
+
+
+def exps_before(g):
+    """exponentials issued before gap g: 5 per 4 gaps through the S phase (gaps 0..31: 40), then one per gap, the last at gap 54 (two in
+    gap 32), so that with the consumers up to LAG = 2 gaps behind, the pack of the last pair (gap <= 56) precedes its MFMA (gap 57)."""
+    if g <= 32:
+        return g + (g + 3) // 4
+    return min(64, 41 + (g - 32))
+
+
+def frag_insts(f):
+    return 2 if 16 <= f < 32 else 1
+
+
+def wait_for(f):    # first MFMA of an even fragment f: f and f+1 landed = all but the reads of f+2 .. f+PF-1 outstanding
+    return sum(frag_insts(f + i) for i in range(2, PF))
+
+
+ABL = os.environ.get("HV_W4_ABL", "")      # timing-only ablations (WRONG results): v = no softmax VALU, l = no LDS fragment reads, d = no DMA, w = no lgkmcnt waits
+STAMPS = os.environ.get("HV_W4_STAMPS") == "1"     # diagnostic build only (never shipped): s_memtime around the barrier's waits
+
+
+def gen_iter(SC, SN):
+    L = []
+    A = L.append
+    if STAMPS:      # s[90:99] are this build's scratch (clobbered): t0 = iteration start
+        A("s_memtime s[90:91]")
+
+    def s_reg(base, qb, kb, r):
+        return f"v{base + 16 * (2 * qb + kb) + r}"
+
+    def s_tile(base, qb, kb):
+        b = base + 16 * (2 * qb + kb)
+        return f"v[{b}:{b + 15}]"
+
+    def ex_reg(e):
+        return f"v{V_EX + (e % EXR)}"
+
+    ktmp = [V_T0, V_T1]
+    for g in range(64):
+        A(f"; ---- gap {g}")
+        if STAMPS and g in (16, 32, 48):      # phase stamps (each drains the LDS queue: timing of this build only)
+            A("s_memtime s[94:95]")
+            A("s_waitcnt lgkmcnt(0)")
+            A("s_sub_u32 s98, s94, s90")
+            A(f"s_add_u32 %[acc_p{g // 16}], %[acc_p{g // 16}], s98")
+        dma = g < 32 and (g & 3) == 3
+        if dma:
+            i = (g >> 2) & 3
+            A(f"s_add_u32 m0, %[{'kdst' if g < 16 else 'vdst'}], {i * 1024}")
+        # ---- MFMA
+        if g < 32:
+            f, qb = g >> 1, g & 1
+            kb, ks = f >> 3, f & 7
+            kf, qf = A_KF + 4 * (f % RING), A_Q + 4 * (qb * 8 + ks)
+            if qb == 0 and f % 2 == 0:
+                A(f"s_waitcnt lgkmcnt({wait_for(f)})")
+            c = f"v[{V_NEGM + 16 * qb}:{V_NEGM + 16 * qb + 15}]" if ks == 0 else s_tile(SN, qb, kb)
+            A(f"v_mfma_f32_32x32x16_bf16 {s_tile(SN, qb, kb)}, a[{kf}:{kf + 3}], a[{qf}:{qf + 3}], {c}")
+        else:
+            j = g - 32
+            kk, db, qb, f = j >> 3, (j & 7) >> 1, j & 1, 16 + (j >> 1)
+            vf, ot = A_VF + 4 * (f % RING), A_O + 16 * (qb * 4 + db)
+            if qb == 0 and f % 2 == 0:
+                A(f"s_waitcnt lgkmcnt({wait_for(f)})")
+            pw = V_PW + 4 * (4 * qb + kk)
+            A(f"v_mfma_f32_32x32x16_bf16 a[{ot}:{ot + 15}], a[{vf}:{vf + 3}], v[{pw}:{pw + 3}], a[{ot}:{ot + 15}]")
+        # ---- barrier: this wave's pieces of K(t+2) / V(t+1) by the counted vmcnt (the 8 youngest = this iteration's), everyone's by the barrier
+        if g == 2 * (32 - PF):
+            if STAMPS:
+                A("s_memtime s[92:93]")
+                A("s_waitcnt lgkmcnt(0)")
+            A("s_waitcnt vmcnt(8)")
+            if STAMPS:
+                A("s_memtime s[94:95]")
+                A("s_waitcnt lgkmcnt(0)")
+            A("s_barrier")
+            if STAMPS:
+                A("s_memtime s[96:97]")
+                A("s_waitcnt lgkmcnt(0)")
+                A("s_sub_u32 s98, s94, s92")
+                A("s_add_u32 %[acc_vm], %[acc_vm], s98")
+                A("s_sub_u32 s98, s96, s94")
+                A("s_add_u32 %[acc_bar], %[acc_bar], s98")
+                A("s_sub_u32 s98, s92, s90")
+                A("s_add_u32 %[acc_pre], %[acc_pre], s98")
+        # ---- packs and row-sum adds of the PREVIOUS gap's exponentials (the MFMA above separates them from their v_exp_f32)
+        if g >= LAG:
+            for e in range(exps_before(g - LAG), exps_before(g - LAG + 1)):
+                kk, qb, j = e >> 4, (e >> 3) & 1, e & 7
+                if j & 1:
+                    A(f"v_cvt_pk_bf16_f32 v{V_PW + 4 * (4 * qb + kk) + (j >> 1)}, {ex_reg(e - 1)}, {ex_reg(e)}")
+            for e in range(exps_before(g - LAG), exps_before(g - LAG + 1)):
+                qb = (e >> 3) & 1
+                acc = (V_L if (e & 1) == 0 else V_L2) + qb
+                A(f"v_add_f32 v{acc}, v{acc}, {ex_reg(e)}")
+        # ---- fragment reads, PF fragments ahead
+        if g % 2 == 0:
+            f2 = g // 2 + PF
+            if f2 < 16 or f2 >= 32:
+                fk = f2 if f2 < 16 else f2 - 32
+                slot = A_KF + 4 * (f2 % RING)
+                ks, kb = fk & 7, fk >> 3
+                addr = f"v{V_VK0}"
+                if ks:
+                    t = ktmp[(f2 >> 0) & 1]
+                    A(f"v_xor_b32 v{t}, {ks << 5:#x}, v{V_VK0}")
+                    addr = f"v{t}"
+                A(f"ds_read_b128 a[{slot}:{slot + 3}], {addr} offset:{kb * 8192}")
+            else:
+                j2 = f2 - 16
+                kk2, db2 = j2 >> 2, j2 & 3
+                slot = A_VF + 4 * (f2 % RING)
+                A(f"ds_read_b64_tr_b16 a[{slot}:{slot + 1}], v{V_VV + db2} offset:{kk2 * 4096}")
+                A(f"ds_read_b64_tr_b16 a[{slot + 2}:{slot + 3}], v{V_VV + db2} offset:{kk2 * 4096 + 2048}")
+        # ---- exponentials of P(t)
+        for e in range(exps_before(g), exps_before(g + 1)):
+            kk, qb, j = e >> 4, (e >> 3) & 1, e & 7
+            A(f"v_exp_f32 {ex_reg(e)}, {s_reg(SC, qb, kk >> 1, 8 * (kk & 1) + j)}")
+        # ---- row max of S'(t+1): two values per gap, chain-complete order
+        if g >= 32:
+            mi = g - 32
+            c = mi >> 3
+            qb, kb, r = c & 1, c >> 1, 2 * (mi & 7)
+            if kb == 0 and r == 0:
+                A(f"v_max_f32 v{V_MX + qb}, {s_reg(SN, qb, kb, r)}, {s_reg(SN, qb, kb, r + 1)}")
+            else:
+                A(f"v_max3_f32 v{V_MX + qb}, v{V_MX + qb}, {s_reg(SN, qb, kb, r)}, {s_reg(SN, qb, kb, r + 1)}")
+        # ---- per-tile address registers: V(t) bases before its first read (gap 24), K(t+2) base after the last K(t+1) read (gap 22)
+        if g == 12:
+            A(f"v_add_u32 v{V_VV}, %[rb0], v{V_VREAD}")
+        if g in (13, 14, 15):
+            A(f"v_xor_b32 v{V_VV + g - 12}, {(g - 12) << 6:#x}, v{V_VV}")
+        if g == 44:
+            A(f"v_add_u32 v{V_VK0}, %[rb2], v{V_KREAD0}")
+        # ---- DMA piece (K(t+3) at gaps 3..15, V(t+2) at gaps 19..31); M0 was written at the top of the gap
+        if dma:
+            i = (g >> 2) & 3
+            if g < 16:
+                A(f"buffer_load_dwordx4 v{V_KOFF + i}, %[krs], 0 offen lds")
+            else:
+                A(f"buffer_load_dwordx4 v{V_VOFF + i}, %[vrs], 0 offen lds")
+    if ABL:
+        def drop(ln):
+            op = ln.split()[0]
+            if "v" in ABL and op in ("v_exp_f32", "v_add_f32", "v_cvt_pk_bf16_f32", "v_max3_f32", "v_max_f32"):
+                return True
+            if "l" in ABL and (op.startswith("ds_read") or op == "v_xor_b32"):
+                return True
+            if "d" in ABL and (op.startswith("buffer_load") or (op == "s_add_u32" and "m0" in ln) or ln.startswith("s_waitcnt vmcnt")):
+                return True
+            if "w" in ABL and ln.startswith("s_waitcnt lgkmcnt") and not STAMPS:
+                return True
+            return False
+        L = [ln for ln in L if not drop(ln)]
+    return L
+
+
+def emit_fn(name, SC, SN):
+    body = gen_iter(SC, SN)
+    text = "\n".join(f'        "{ln}\\n\\t"' if not ln.startswith(";") else f'        "{ln}\\n\\t"' for ln in body)
+    sc = "sA" if SC == 0 else "sB"
+    sn = "sB" if SC == 0 else "sA"
+
+    def tiles(var, base, pre):
+        return ", ".join(f'"{pre}{{v[{base + 16 * (2 * qb + kb)}:{base + 16 * (2 * qb + kb) + 15}]}}"({var}[{qb}][{kb}])' for qb in range(2) for kb in range(2))
+    clob = [f'"v{i}"' for i in list(range(V_PW, V_PW + 32)) + list(range(V_EX, V_EX + EXR)) + [V_T0, V_T1] + list(range(V_VV, V_VV + 4))]
+    dbg_args = ", uint32_t& acc_vm, uint32_t& acc_bar, uint32_t& acc_pre, uint32_t& acc_p1, uint32_t& acc_p2, uint32_t& acc_p3" if STAMPS else ""
+    dbg_out = ', [acc_vm] "+s"(acc_vm), [acc_bar] "+s"(acc_bar), [acc_pre] "+s"(acc_pre), [acc_p1] "+s"(acc_p1), [acc_p2] "+s"(acc_p2), [acc_p3] "+s"(acc_p3)' if STAMPS else ""
+    if STAMPS:
+        clob += [f'"s{i}"' for i in range(90, 99)]
+    return f'''// iteration with S'(t) in {sc} and S'(t+1) produced in {sn}
+__device__ __forceinline__ void {name}(f32x16 (&sA)[2][2], f32x16 (&sB)[2][2], const f32x16 (&negm)[2], float (&l)[2], float (&l2)[2], float (&mx)[2], uint32_t& vk0,
+                                       uint32_t kread0, uint32_t vread, u32x4 koff, u32x4 voff, u32x4 krs, u32x4 vrs, uint32_t kdst,
+                                       uint32_t vdst, uint32_t rb0, uint32_t rb2{dbg_args}) {{
+    asm volatile(
+{text}
+        : {tiles(sn, SN, "=")}, "+{{v{V_L}}}"(l[0]), "+{{v{V_L + 1}}}"(l[1]), "+{{v{V_L2}}}"(l2[0]), "+{{v{V_L2 + 1}}}"(l2[1]), "={{v{V_MX}}}"(mx[0]), "={{v{V_MX + 1}}}"(mx[1]),
+          "+{{v{V_VK0}}}"(vk0){dbg_out}
+        : {tiles(sc, SC, "")}, "{{v[{V_NEGM}:{V_NEGM + 15}]}}"(negm[0]), "{{v[{V_NEGM + 16}:{V_NEGM + 31}]}}"(negm[1]),
+          "{{v{V_KREAD0}}}"(kread0), "{{v{V_VREAD}}}"(vread), "{{v[{V_KOFF}:{V_KOFF + 3}]}}"(koff), "{{v[{V_VOFF}:{V_VOFF + 3}]}}"(voff),
+          [krs] "s"(krs), [vrs] "s"(vrs), [kdst] "s"(kdst), [vdst] "s"(vdst), [rb0] "s"(rb0), [rb2] "s"(rb2)
+        : {", ".join(clob)}, "scc", "memory", HV_CLOBBER_ALL_AGPRS);
+}}
+'''
+
+
+def main():
+    hdr = ("// GENERATED by tools/gen_attn_w4_asm.py - do not edit by hand (tests/test_capi_cpu.py checks it is up to date).\n"
+           "// The steady-state iteration of attn_fwd_kernel_w4 as one inline-asm statement per S-buffer role; register map and schedule:\n"
+           "// the generator's docstring and the header of hv_attention_w4.hip.\n")
+    text = hdr + emit_fn("w4_iter_ab", 0, 64) + "\n" + emit_fn("w4_iter_ba", 64, 0)
+    return text
+
+
+if __name__ == "__main__":
+    t = main()
+    with open(OUT, "w") as f:
+        f.write(t)
+    print(f"wrote {OUT}: {t.count(chr(10))} lines")
