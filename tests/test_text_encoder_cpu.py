@@ -105,3 +105,48 @@ def test_save_videos_grid_frames_and_container(tmp_path):
         from PIL import Image
         im = Image.open(out)
         assert im.n_frames == 4 and im.size == (2 * 8 + 6, 10)
+
+
+def test_text_encoder_vs_reference_executed_golden(golden, tmp_path):
+    """SURVEY.md 8f row 4 pinned: tests/golden/text_encoder.npz was produced by tools/make_golden_text.py, which IMPORTS the reference's
+    hyvideo/text_encoder and runs ITS TextEncoder.text2tokens / encode (:220-339) on tiny random LLaMA / CLIP models saved with
+    save_pretrained.  Here the same models are rebuilt from the weights the fixture carries and this repo's wrapper must return the
+    same token ids, masks and hidden states: video and image templates with instruction-token cropping, hidden_state_skip_layer = 2
+    with the final norm, skip layer without it, the plain last layer via output_key, truncation, CLIP's pooled output."""
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer, LlamaConfig, LlamaModel
+    from hunyuanvideo_efficiency_amd.text_encoder import TextEncoder
+    from tests.toy_text_models import CLIP_CFG, LLM_CFG, TPL_IMAGE, TPL_VIDEO, toy_llm_tokenizer, write_clip_tokenizer_files
+    g = golden("text_encoder")
+    llm = LlamaModel(LlamaConfig(**LLM_CFG)).eval()
+    llm.load_state_dict({k[len("llm.w."):]: v for k, v in g.items() if k.startswith("llm.w.")}, strict=True)
+    enc = TextEncoder("llm", max_length=8 + TPL_VIDEO["crop_start"], text_encoder_precision="fp32", tokenizer_type="llm",
+                      prompt_template=TPL_IMAGE, prompt_template_video=TPL_VIDEO, hidden_state_skip_layer=2, apply_final_norm=True,
+                      model=llm, tokenizer=toy_llm_tokenizer())
+    for name, text, dt in (("video", "a cat walks on grass", "video"), ("image", "red car", "image"),
+                           ("video_long", "a cat walks on grass slowly a cat walks on grass slowly", "video")):
+        toks = enc.text2tokens(text, data_type=dt)
+        assert torch.equal(toks["input_ids"], g[f"llm.{name}.input_ids"]) and torch.equal(toks["attention_mask"], g[f"llm.{name}.attention_mask"])
+        o = enc.encode(toks, data_type=dt)
+        torch.testing.assert_close(o.hidden_state, g[f"llm.{name}.hidden_state"], rtol=1e-5, atol=1e-6)
+        assert torch.equal(o.attention_mask, g[f"llm.{name}.out_mask"])
+    enc.hidden_state_skip_layer = None
+    toks = enc.text2tokens("a red car", data_type="image")
+    assert torch.equal(toks["input_ids"], g["llm.last.input_ids"])
+    o = enc.encode(toks, data_type="image", output_hidden_states=True)
+    torch.testing.assert_close(o.hidden_state, g["llm.last.hidden_state"], rtol=1e-5, atol=1e-6)
+    assert len(o.hidden_states_list) == int(g["llm.last.n_hidden_states"])
+    enc.apply_final_norm = False
+    o = enc.encode(toks, data_type="image", hidden_state_skip_layer=1)
+    torch.testing.assert_close(o.hidden_state, g["llm.skip1_nonorm.hidden_state"], rtol=1e-5, atol=1e-6)
+    # CLIP-L: pooled output (the reference's loader line for CLIP is an AttributeError under transformers 5.x - the fixture's note;
+    # its text2tokens / encode produced these vectors)
+    clip = CLIPTextModel(CLIPTextConfig(**CLIP_CFG)).eval()
+    clip.load_state_dict({k[len("clip.w."):]: v for k, v in g.items() if k.startswith("clip.w.")}, strict=True)
+    write_clip_tokenizer_files(str(tmp_path))
+    enc2 = TextEncoder("clipL", max_length=10, text_encoder_precision="fp32", tokenizer_type="clipL", model=clip,
+                       tokenizer=CLIPTokenizer.from_pretrained(str(tmp_path), max_length=77))
+    toks = enc2.text2tokens("a red car")
+    assert torch.equal(toks["input_ids"], g["clip.input_ids"]) and torch.equal(toks["attention_mask"], g["clip.attention_mask"])
+    o = enc2.encode(toks)
+    torch.testing.assert_close(o.hidden_state, g["clip.hidden_state"], rtol=1e-5, atol=1e-6)
+    assert torch.equal(o.attention_mask, g["clip.out_mask"])
