@@ -13,6 +13,14 @@ import torch
 from ... import vae_ops
 
 
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
+    """pipeline_hunyuan_video.py:56-71 (Common Diffusion Noise Schedules and Sample Steps are Flawed, section 3.4)."""
+    std_text = noise_pred_text.std(dim=list(range(1, noise_pred_text.ndim)), keepdim=True)
+    std_cfg = noise_cfg.std(dim=list(range(1, noise_cfg.ndim)), keepdim=True)
+    noise_pred_rescaled = noise_cfg * (std_text / std_cfg)
+    return guidance_rescale * noise_pred_rescaled + (1 - guidance_rescale) * noise_cfg
+
+
 class HunyuanVideoPipeline:
     def __init__(self, vae, transformer, scheduler, args=None, progress_bar_config=None, text_encoder=None, text_encoder_2=None):
         self.vae, self.transformer, self.scheduler, self.args = vae, transformer, scheduler, args
@@ -39,11 +47,11 @@ class HunyuanVideoPipeline:
         return latents
 
     def encode_prompt(self, prompt, device, num_videos_per_prompt=1, do_classifier_free_guidance=False, negative_prompt=None,
-                      prompt_embeds=None, attention_mask=None, text_encoder=None, data_type="image", **unused):
-        """pipeline_hunyuan_video.py:238-420 for the CFG-distilled model (no negative branch): tokenise with the encoder's
-        template, encode, repeat per requested video.  Returns (prompt_embeds, None, attention_mask, None) like the reference."""
-        if do_classifier_free_guidance:
-            raise NotImplementedError("classifier-free guidance batch: the shipped model is CFG-distilled (--cfg-scale 1.0)")
+                      prompt_embeds=None, attention_mask=None, negative_prompt_embeds=None, negative_attention_mask=None,
+                      text_encoder=None, data_type="image", **unused):
+        """pipeline_hunyuan_video.py:238-420: tokenise with the encoder's template, encode, repeat per requested video; with
+        classifier-free guidance also the negative prompt ("" when none is given, :373-374).
+        Returns (prompt_embeds, negative_prompt_embeds, attention_mask, negative_attention_mask) like the reference."""
         text_encoder = self.text_encoder if text_encoder is None else text_encoder
         if prompt_embeds is None:
             out = text_encoder.encode(text_encoder.text2tokens(prompt, data_type=data_type), data_type=data_type, device=device)
@@ -52,7 +60,26 @@ class HunyuanVideoPipeline:
                 attention_mask = attention_mask.to(device).repeat_interleave(num_videos_per_prompt, dim=0)
         dtype = text_encoder.dtype if text_encoder is not None else prompt_embeds.dtype
         prompt_embeds = prompt_embeds.to(dtype=dtype, device=device).repeat_interleave(num_videos_per_prompt, dim=0)
-        return prompt_embeds, None, attention_mask, None
+        if not do_classifier_free_guidance:
+            return prompt_embeds, None, attention_mask, None
+        if negative_prompt_embeds is None:
+            batch = 1 if isinstance(prompt, str) or prompt is None else len(prompt)
+            if negative_prompt is None:
+                uncond = [""] * batch
+            elif prompt is not None and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} != {type(prompt)}.")
+            elif isinstance(negative_prompt, str):
+                uncond = [negative_prompt]
+            elif batch != len(negative_prompt):
+                raise ValueError(f"`negative_prompt` has batch size {len(negative_prompt)}, but `prompt` has batch size {batch}.")
+            else:
+                uncond = negative_prompt
+            nout = text_encoder.encode(text_encoder.text2tokens(uncond, data_type=data_type), data_type=data_type, device=device)
+            negative_prompt_embeds, negative_attention_mask = nout.hidden_state, nout.attention_mask
+            if negative_attention_mask is not None:
+                negative_attention_mask = negative_attention_mask.to(device).repeat_interleave(num_videos_per_prompt, dim=0)
+        negative_prompt_embeds = negative_prompt_embeds.to(dtype=dtype, device=device).repeat_interleave(num_videos_per_prompt, dim=0)
+        return prompt_embeds, negative_prompt_embeds, attention_mask, negative_attention_mask
 
     @torch.no_grad()
     def __call__(self, prompt_embeds: Optional[torch.Tensor] = None, prompt_mask: Optional[torch.Tensor] = None,
@@ -62,24 +89,37 @@ class HunyuanVideoPipeline:
                  freqs_cis=None, output_type: str = "pil", return_dict: bool = True, vae_ver: str = "884-16c-hy",
                  enable_tiling: bool = True, n_tokens: Optional[int] = None, callback: Optional[Callable] = None,
                  callback_steps: int = 1, prompt=None, negative_prompt=None, num_videos_per_prompt: int = 1, data_type: str = "video",
-                 is_progress_bar: bool = False, attention_mask: Optional[torch.Tensor] = None, device=None):
+                 is_progress_bar: bool = False, attention_mask: Optional[torch.Tensor] = None, device=None,
+                 negative_prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_mask: Optional[torch.Tensor] = None,
+                 negative_prompt_embeds_2: Optional[torch.Tensor] = None, guidance_rescale: float = 0.0):
         """Either the reference's keyword surface (`prompt=...`, text encoders attached: pipeline_hunyuan_video.py:664-1100) or
         pre-computed `prompt_embeds` / `prompt_mask` / `prompt_embeds_2` (synthetic benchmarks, tests)."""
-        if guidance_scale > 1.0:
-            raise NotImplementedError("classifier-free guidance batch: the shipped model is CFG-distilled (--cfg-scale 1.0)")
+        # classifier-free guidance (:966-1019; the non-distilled model): batch [uncond | cond] through the transformer, then
+        # uncond + scale (cond - uncond); the CFG-distilled model runs with guidance_scale = 1 and never doubles the batch
+        do_cfg = guidance_scale > 1.0
         if prompt is not None:
             if self.text_encoder is None:
                 raise ValueError("prompt given but the pipeline has no text_encoder")
             if not isinstance(prompt, str) or num_videos_per_prompt != 1:
                 raise NotImplementedError("batch 1: one prompt, one video per call")
             device = device if device is not None else self.transformer.img_in.proj.weight.device
-            prompt_embeds, _, prompt_mask, _ = self.encode_prompt(prompt, device, num_videos_per_prompt, False, data_type=data_type)
+            prompt_embeds, negative_prompt_embeds, prompt_mask, negative_prompt_mask = self.encode_prompt(
+                prompt, device, num_videos_per_prompt, do_cfg, negative_prompt, data_type=data_type)
             if self.text_encoder_2 is not None:     # CLIP pooled vector (:869-886)
-                prompt_embeds_2 = self.encode_prompt(prompt, device, num_videos_per_prompt, False, text_encoder=self.text_encoder_2,
-                                                     data_type=data_type)[0]
+                prompt_embeds_2, negative_prompt_embeds_2, _, _ = self.encode_prompt(
+                    prompt, device, num_videos_per_prompt, do_cfg, negative_prompt, text_encoder=self.text_encoder_2, data_type=data_type)
         elif prompt_mask is None and attention_mask is not None:
             prompt_mask = attention_mask
         device = prompt_embeds.device
+        n_cond = prompt_embeds.shape[0]
+        if do_cfg:       # one batch [uncond | cond] (:896-904)
+            if negative_prompt_embeds is None:
+                raise ValueError("guidance_scale > 1 needs negative_prompt_embeds (or a prompt + text encoders)")
+            prompt_embeds = torch.cat([negative_prompt_embeds.to(prompt_embeds), prompt_embeds])
+            if prompt_mask is not None:
+                prompt_mask = torch.cat([negative_prompt_mask.to(prompt_mask), prompt_mask])
+            if prompt_embeds_2 is not None:
+                prompt_embeds_2 = torch.cat([negative_prompt_embeds_2.to(prompt_embeds_2), prompt_embeds_2])
         # 4. timesteps (:907-917)
         self.scheduler.set_timesteps(num_inference_steps, device=device, n_tokens=n_tokens)
         timesteps = self.scheduler.timesteps
@@ -88,14 +128,14 @@ class HunyuanVideoPipeline:
             video_length = (video_length - 1) // 4 + 1
         elif "888" in vae_ver:
             video_length = (video_length - 1) // 8 + 1
-        latents = self.prepare_latents(prompt_embeds.shape[0], self.transformer.config.in_channels, height, width, video_length,
+        latents = self.prepare_latents(n_cond, self.transformer.config.in_channels, height, width, video_length,
                                        prompt_embeds.dtype, device, generator, latents)
         self._num_timesteps = len(timesteps)
         # 7. denoising loop (:955-1045); autocast(bf16) is the kernels' native contract
         for i, t in enumerate(timesteps):
             if self.interrupt:
                 continue
-            latent_model_input = self.scheduler.scale_model_input(latents, t)
+            latent_model_input = self.scheduler.scale_model_input(torch.cat([latents] * 2) if do_cfg else latents, t)
             t_expand = t.repeat(latent_model_input.shape[0])
             guidance_expand = None
             if embedded_guidance_scale is not None:
@@ -104,6 +144,11 @@ class HunyuanVideoPipeline:
             noise_pred = self.transformer(latent_model_input, t_expand, text_states=prompt_embeds, text_mask=prompt_mask,
                                           text_states_2=prompt_embeds_2, freqs_cos=freqs_cis[0], freqs_sin=freqs_cis[1],
                                           guidance=guidance_expand, return_dict=True)["x"]
+            if do_cfg:
+                noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
+                noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
+                if guidance_rescale > 0.0:
+                    noise_pred = rescale_noise_cfg(noise_pred, noise_pred_text, guidance_rescale=guidance_rescale)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             if callback is not None and i % callback_steps == 0:
                 callback(i // getattr(self.scheduler, "order", 1), t, latents)

@@ -372,11 +372,31 @@ class HYVideoDiffusionTransformer(nn.Module):
                 text_states_2: Optional[torch.Tensor] = None, freqs_cos: Optional[torch.Tensor] = None,
                 freqs_sin: Optional[torch.Tensor] = None, guidance: torch.Tensor = None,
                 return_dict: bool = True) -> Union[torch.Tensor, Dict[str, torch.Tensor]]:
-        if x.shape[0] != 1:
-            raise NotImplementedError("batch size 1 only: the shipped model is CFG-distilled (config.py:339-341) "
-                                      "and the pipeline never doubles the batch")
+        """models.py:595-695 of the reference.  Batch B > 1 (the pipeline's classifier-free-guidance batch [uncond | cond],
+        pipeline_hunyuan_video.py:966-1019; the non-distilled "HYVideo-T/2") runs as B passes through the SAME activation workspace:
+        the reference's batched forward is B independent samples (per-sample cu_seqlens attention, per-sample modulation), and at
+        S = 119,056 one sample already fills the chip, so a batched launch would buy nothing and double the 8 GB workspace."""
         if self.dtype != BF16:
             raise TypeError(f"parameters must be bf16 (got {self.dtype}); build with dtype=torch.bfloat16 or call .to()")
+        B = x.shape[0]
+        if B == 1:
+            out = self._forward_one(x, t, text_states, text_mask, text_states_2, freqs_cos, freqs_sin, guidance, 0)
+        else:
+            t = t.reshape(-1)
+            if t.numel() == 1:
+                t = t.expand(B)
+            outs = []
+            for b in range(B):
+                g_b = None if guidance is None else guidance.reshape(-1)[b:b + 1] if guidance.numel() > 1 else guidance
+                outs.append(self._forward_one(x[b:b + 1], t[b:b + 1], text_states, text_mask,
+                                              None if text_states_2 is None else text_states_2[b:b + 1], freqs_cos, freqs_sin, g_b, b))
+            out = torch.cat(outs, 0)
+        if return_dict:
+            return {"x": out}
+        return out
+
+    def _forward_one(self, x, t, text_states, text_mask, text_states_2, freqs_cos, freqs_sin, guidance, b: int) -> torch.Tensor:
+        """One sample: x [1,C,T,H,W]; text_states / text_mask are the WHOLE batch tensors (the refiner cache hangs on them), row b is used."""
         dev = x.device
         _, _, ot, oh, ow = x.shape
         tt, th, tw = ot // self.patch_size[0], oh // self.patch_size[1], ow // self.patch_size[2]
@@ -394,25 +414,35 @@ class HYVideoDiffusionTransformer(nn.Module):
 
         # ---- embed image and text (models.py:634-642)
         self.img_in.run(x[0].to(torch.float32).contiguous(), ws, s_img)
-        mask = text_mask if self.use_attention_mask else None
+        mask_all = text_mask if self.use_attention_mask else None
         # per-prompt cache of the refiner's timestep-independent prefix: stashed on the caller's text_states tensor OBJECT (the
-        # pipeline passes the same tensor every step; never keyed on an address) and valid only for the SAME mask object at the
-        # same _version and for unmodified refiner parameters (every parameter's _version enters the key: an in-place update of
-        # any of them - optimizer step, load_state_dict - drops the cache; replacing a parameter's .data without a version bump
-        # is not detectable and needs `del text_states._hv_txt_cache`: inference-only use)
-        tc = getattr(text_states, "_hv_txt_cache", None)
-        key = (text_states._version, None if mask is None else mask._version, id(self.txt_in),
+        # pipeline passes the same tensor every step; never keyed on an address), one entry per batch row, and valid only for the
+        # SAME mask object at the same _version and for unmodified refiner parameters (every parameter's _version enters the key:
+        # an in-place update of any of them - optimizer step, load_state_dict - drops the cache; replacing a parameter's .data
+        # without a version bump is not detectable and needs `del text_states._hv_txt_cache`: inference-only use)
+        tc_all = getattr(text_states, "_hv_txt_cache", None)
+        key = (text_states._version, None if mask_all is None else mask_all._version, id(self.txt_in),
                tuple(p._version for p in self.txt_in.parameters()))
-        if tc is None or tc.get("key") != key or tc.get("mask") is not mask:
-            tc = {"key": key, "mask": mask, "text_bf16": text_states[0].to(BF16).contiguous()}
+        if tc_all is None or tc_all.get("key") != key or tc_all.get("mask") is not mask_all:
+            tc_all = {"key": key, "mask": mask_all, "rows": {}}
             try:
-                text_states._hv_txt_cache = tc
+                text_states._hv_txt_cache = tc_all
             except (AttributeError, RuntimeError):
                 pass
+        tc = tc_all["rows"].get(b)
+        if tc is None:
+            tc = tc_all["rows"][b] = {"text_bf16": text_states[b].to(BF16).contiguous(),
+                                      "mask": None if mask_all is None else (mask_all if mask_all.shape[0] == 1 else mask_all[b:b + 1]),
+                                      "mask_cu": None if text_mask is None else (text_mask if text_mask.shape[0] == 1 else text_mask[b:b + 1])}
+        mask = tc["mask"]
         self.txt_in.run(tc["text_bf16"], t32, mask, out=ws.x[s_img:], cache=tc)
 
         # ---- cu_seqlens (models.py:648): segment 1 = img + valid text, segment 2 = padding text
-        cu1 = s_img + (n_valid_text(text_mask) if text_mask is not None else s_txt)
+        # (the row's mask view is kept in the cache entry: n_valid_text stashes its host-side count on that tensor object)
+        if text_mask is not None and tc.get("mask_cu_src") is not text_mask:
+            tc["mask_cu"] = text_mask if text_mask.shape[0] == 1 else text_mask[b:b + 1]
+            tc["mask_cu_src"] = text_mask
+        cu1 = s_img + (n_valid_text(tc["mask_cu"]) if text_mask is not None else s_txt)
         cos = freqs_cos.to(device=dev, dtype=torch.float32).contiguous() if freqs_cos is not None else None
         sin = freqs_sin.to(device=dev, dtype=torch.float32).contiguous() if freqs_sin is not None else None
 
@@ -423,10 +453,7 @@ class HYVideoDiffusionTransformer(nn.Module):
 
         img = self.final_layer.run(ws, s_img, vec)                       # [S_img, 64]
         out = ops.unpatchify(img, self.unpatchify_channels, ot, oh, ow)  # [C,T,H,W] bf16
-        out = out[None]
-        if return_dict:
-            return {"x": out}
-        return out
+        return out[None]
 
     def params_count(self):
         counts = {

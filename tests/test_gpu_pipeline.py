@@ -123,3 +123,55 @@ def test_pipeline_prompt_surface_with_text_encoders():
     assert v1.shape == (1, 3, frames, height, width) and torch.equal(v1, v2)
     with pytest.raises(ValueError):
         HunyuanVideoPipeline(vae, model, pipe.scheduler)(prompt="x", **kw)
+
+
+def test_pipeline_classifier_free_guidance_batch_vs_oracle():
+    """The CFG branch of the reference pipeline (pipeline_hunyuan_video.py:966-1019: batch [uncond | cond] through the transformer,
+    uncond + scale (cond - uncond), optional guidance_rescale :56-71) on a non-distilled tiny model (guidance_embed=False, what
+    "HYVideo-T/2" is): the batch-2 forward (two passes through one workspace) and the combination against the oracle run per
+    branch in the bf16-emulated contract.  Different prompts AND different valid-token counts in the two branches."""
+    from hunyuanvideo_efficiency_amd.builders import build_model
+    from hunyuanvideo_efficiency_amd.diffusion.schedulers import FlowMatchDiscreteScheduler
+    from hunyuanvideo_efficiency_amd.diffusion.pipelines import HunyuanVideoPipeline
+    from hunyuanvideo_efficiency_amd.diffusion.pipelines.pipeline_hunyuan_video import rescale_noise_cfg
+    from hunyuanvideo_efficiency_amd.inference import get_rotary_pos_embed
+    cfg = syn.tiny_config()
+    cfg.guidance_embed = False
+    model = build_model(cfg, DEV, seed=0)
+    pipe = HunyuanVideoPipeline(None, model, FlowMatchDiscreteScheduler(shift=7.0, reverse=True, solver="euler"), types.SimpleNamespace())
+    frames, height, width, n_steps, scale, resc = 17, 128, 128, 2, 3.5, 0.3
+    lt, lh, lw = (frames - 1) // 4 + 1, height // 8, width // 8
+    x0, ts, tm, ts2 = syn.synth_dit_inputs(cfg, (lt, lh, lw), 32, 11, seed=5)
+    _, nts, ntm, nts2 = syn.synth_dit_inputs(cfg, (lt, lh, lw), 32, 4, seed=6)          # the "negative prompt": other states, 4 valid tokens
+    freqs = get_rotary_pos_embed(model, frames, height, width, "884-16c-hy", 256, device=DEV)
+    f16 = lambda t: t.to(torch.float16).to(DEV)
+    kw = dict(height=height, width=width, video_length=frames, num_inference_steps=n_steps, embedded_guidance_scale=None, freqs_cis=freqs,
+              output_type="latent", n_tokens=freqs[0].shape[0])
+    got = pipe(f16(ts), tm.to(DEV), f16(ts2), guidance_scale=scale, guidance_rescale=resc, latents=x0.clone(),
+               negative_prompt_embeds=f16(nts), negative_prompt_mask=ntm.to(DEV), negative_prompt_embeds_2=f16(nts2), **kw).videos
+    # oracle: per step, the two branches separately, combined in the pipeline's dtype (bf16 model outputs)
+    E = RD.Prec(True)
+    sd = {k: p.float().cpu() for k, p in model.state_dict().items()}
+    cos, sin = RD.rope_tables([lt, lh // 2, lw // 2], cfg.rope_dim_list, 256.0)
+    sig = RD.flow_sigmas(n_steps, 7.0)
+    tsteps = RD.flow_timesteps(sig)
+    lat = x0.clone().float()
+    h = lambda t: t.to(torch.float16).float()
+    for i in range(n_steps):
+        vu = RD.dit_forward(sd, cfg, lat, tsteps[i:i + 1], h(nts), ntm, h(nts2), cos, sin, None, E).to(torch.bfloat16)
+        vc = RD.dit_forward(sd, cfg, lat, tsteps[i:i + 1], h(ts), tm, h(ts2), cos, sin, None, E).to(torch.bfloat16)
+        v = vu + scale * (vc - vu)
+        v = rescale_noise_cfg(v, vc, guidance_rescale=resc)
+        lat = RD.euler_step(lat, v.float(), sig, i)
+    ref = (lat / 2 + 0.5).clamp(0, 1)
+    assert 0.2 < float(((ref > 0) & (ref < 1)).float().mean())
+    err = float((got - ref).abs().max())
+    assert err < 3e-2, err            # CFG amplifies the per-branch bf16 drift (2e-2 bar, test_gpu_model.py) by the guidance scale
+    assert float((got - ref).abs().mean()) < 3e-3
+    # and the batch-2 forward itself == the two single forwards, bit for bit (same kernels, same workspace)
+    t = torch.tensor([tsteps[0]], device=DEV)
+    both = model(torch.cat([x0, x0]).to(DEV), t.repeat(2), text_states=torch.cat([f16(nts), f16(ts)]), text_mask=torch.cat([ntm, tm]).to(DEV),
+                 text_states_2=torch.cat([f16(nts2), f16(ts2)]), freqs_cos=freqs[0], freqs_sin=freqs[1], guidance=None)["x"]
+    one_u = model(x0.to(DEV), t, text_states=f16(nts), text_mask=ntm.to(DEV), text_states_2=f16(nts2), freqs_cos=freqs[0], freqs_sin=freqs[1])["x"]
+    one_c = model(x0.to(DEV), t, text_states=f16(ts), text_mask=tm.to(DEV), text_states_2=f16(ts2), freqs_cos=freqs[0], freqs_sin=freqs[1])["x"]
+    assert torch.equal(both[0:1], one_u) and torch.equal(both[1:2], one_c)

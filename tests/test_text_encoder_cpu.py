@@ -85,8 +85,13 @@ def test_pipeline_encode_prompt_glue():
     pipe = HunyuanVideoPipeline(None, None, None, text_encoder=enc)
     emb, neg, mask, negmask = pipe.encode_prompt("a cat walks", "cpu", 1, False, data_type="video")
     assert emb.shape == (1, 8, 32) and mask.tolist() == [[1, 1, 1, 0, 0, 0, 0, 0]] and neg is None and negmask is None
-    with pytest.raises(NotImplementedError):
-        pipe.encode_prompt("a cat", "cpu", 1, True)
+    # classifier-free guidance: the negative prompt ("" by default, pipeline_hunyuan_video.py:373-374) is encoded the same way
+    emb_c, emb_u, mask_c, mask_u = pipe.encode_prompt("a cat walks", "cpu", 1, True, data_type="video")
+    assert torch.equal(emb_c, emb) and emb_u.shape == emb.shape and mask_u.tolist() == [[0] * 8]
+    _, emb_n, _, mask_n = pipe.encode_prompt("a cat walks", "cpu", 1, True, "red car", data_type="video")
+    assert mask_n.tolist() == [[1, 1, 0, 0, 0, 0, 0, 0]] and not torch.equal(emb_n, emb_u)
+    with pytest.raises(TypeError):
+        pipe.encode_prompt("a cat", "cpu", 1, True, ["red car"], data_type="video")
 
 
 def test_save_videos_grid_frames_and_container(tmp_path):
