@@ -41,6 +41,7 @@ def parse_args():
     p.add_argument("--vae-path", default=None, help="directory with the reference's VAE config.json + pytorch_model.pt")
     p.add_argument("--prompt", default=None, help="text prompt; needs --text-encoder-path (+ --text-encoder-2-path). Default: synthetic "
                                                    "prompt embeddings (no text-encoder checkpoints exist in this environment)")
+    p.add_argument("--neg-prompt", default=None, help="negative prompt of the classifier-free-guidance branch (--cfg-scale > 1; default \"\")")
     p.add_argument("--text-encoder-path", default=None, help="HF directory of the LLM text encoder (+ tokenizer)")
     p.add_argument("--text-encoder-2-path", default=None, help="HF directory of CLIP-L (+ tokenizer)")
     p.add_argument("--text-encoder-precision", default="fp16")
