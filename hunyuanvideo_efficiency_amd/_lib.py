@@ -17,7 +17,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhv_kernels.so")
 TORCH_OPS_PATH = os.path.join(_HERE, "lib", "libhv_torch_ops.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
