@@ -37,7 +37,8 @@ if "SQ_WAVE_CYCLES" in counters:
     wc = counters["SQ_WAVE_CYCLES"] * 4
     # matrix pipe busy per SIMD: MFMA_BUSY is summed over waves; with w waves per SIMD the pipe's busy fraction is w * busy / wave_cycles.
     # every profiled kernel here runs 512-thread workgroups at one workgroup per CU = 2 waves per SIMD.
-    out["mfma_busy_frac_per_simd"] = 2 * counters["SQ_VALU_MFMA_BUSY_CYCLES"] / wc
+    waves_per_simd = 1 if "attn_fwd_kernel" in kname else 2      # attn_fwd_kernel_w4: 256-thread workgroups, one wave per SIMD
+    out["mfma_busy_frac_per_simd"] = waves_per_simd * counters["SQ_VALU_MFMA_BUSY_CYCLES"] / wc
     out["wait_any_frac"] = counters["SQ_WAIT_ANY"] * 4 / wc
     out["wait_inst_any_frac"] = counters["SQ_WAIT_INST_ANY"] * 4 / wc
 if "GRBM_GUI_ACTIVE" in counters and ms:
