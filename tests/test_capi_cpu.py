@@ -137,3 +137,33 @@ def test_generated_attention_iteration_is_up_to_date_and_consistent():
             assert not [x for x in gaps[gi + 2] if x.startswith("s_waitcnt lgkmcnt")]
             frag2 = int(re.findall(r"a\[(\d+):\d+\]", mf2)[1 if gi + 2 >= 32 else 0])
             assert not any(r in (frag2, frag2 + 2) for r in pending), (gi, n, frag2, pending)
+
+
+def test_attention_kernel_generated_code_audit(tmp_path):
+    """hv_attention_w4.hip owns the accumulator half of the register file by literal names, so what hipcc does around the asm matters:
+    compile it for gfx950 with -save-temps and require (cdna_hip_programming.md 5.7 item 4) no VGPR spills, no scratch, all 256
+    accumulator registers allocated, and not one compiler-generated v_accvgpr_* outside ASMSTART/ASMEND (hipcc parks long-lived
+    values in the accumulator half when it is short of registers - that would be a silent write into O)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "hunyuanvideo_efficiency_amd", "csrc", "hv_attention_w4.hip")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-save-temps=obj", "-c", src,
+                    "-o", str(tmp_path / "w4.o")], check=True, cwd=str(tmp_path), capture_output=True)
+    asm = open(tmp_path / "hv_attention_w4-hip-amdgcn-amd-amdhsa-gfx950.s").read()
+    meta = {k: int(v) for k, v in re.findall(r"\.(vgpr_spill_count|private_segment_fixed_size|agpr_count|sgpr_spill_count):\s+(\d+)", asm)}
+    assert meta["vgpr_spill_count"] == 0 and meta["private_segment_fixed_size"] == 0 and meta["agpr_count"] == 256, meta
+    inside, bad = False, []
+    for i, ln in enumerate(asm.split("\n")):
+        if "#ASMSTART" in ln:
+            inside = True
+        elif "#ASMEND" in ln:
+            inside = False
+        elif not inside and "v_accvgpr" in ln:
+            bad.append((i, ln.strip()))
+    assert not bad, bad[:5]
+    assert "scratch_" not in asm
