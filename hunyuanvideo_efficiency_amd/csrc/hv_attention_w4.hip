@@ -293,13 +293,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
         asm volatile("" : "+v"(negm[0]), "+v"(negm[1]));
     };
 
-    // ------------------------------------------------------------------------------------------------ steady-state iteration
-    // consumes Sc = S'(t) with row maxima mx_c, produces Sn = S'(t+1) and mx_n.  On entry: fragments 0, 1 of K(t+1) are in flight
-    // into K slots 0, 1 (issued at gaps 60, 62 of the previous iteration / the prologue), vk[] points at K(t+1)'s buffer,
-    // K(t+2) and V(t+1) have landed or are in flight (retired by this iteration's barrier).
-    // FULL: t + 3 < ntiles (both DMAs of this iteration exist, the tile it produces is not the last): no guards, counted vmcnt.
-    auto body = [&](f32x16 (&Sc)[2][2], f32x16 (&Sn)[2][2], int t, const float (&mx_c)[2], float (&mx_n)[2], auto full_c) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_c)::value;
+    // ------------------------------------------------------------------------------------------------ tail iteration
+    // The SAME 64-gap schedule as the generated steady-state statement (hv_attention_w4_loop.inc), as compiler-scheduled C++ with
+    // one asm statement per MFMA / LDS read / pinned VALU instruction and compiler-allocated arch VGPRs: it runs the <= 4
+    // iterations of a workgroup that cannot use the steady-state statement - a DMA of theirs does not exist any more (t + 3 >=
+    // ntiles: guarded issue, full vmcnt drain at the barrier) or the tile they produce is the ragged last one (masked row max
+    // after the gaps).  Consumes Sc = S'(t) with row maxima mx_c, produces Sn = S'(t+1) and mx_n.  On entry: fragments 0 .. PF-1 of
+    // K(t+1) are in flight into K slots 0 .. PF-1, vk0 points at K(t+1)'s buffer, K(t+2) and V(t+1) have landed or are in flight.
+    auto body = [&](f32x16 (&Sc)[2][2], f32x16 (&Sn)[2][2], int t, const float (&mx_c)[2], float (&mx_n)[2]) __attribute__((always_inline)) {
+        constexpr bool FULL = false;
         if (__any(mx_c[0] > THR || mx_c[1] > THR)) raise_max(Sc, mx_c);
         // ring positions as LDS byte offsets, rotated by the caller (no division): rb0 = buffer of tile t (V(t); K(t+3) is DMA'd
         // over K(t)), rb2 = buffer of tile t+2 (K(t+2): next S phase; V(t+2) is DMA'd over V(t-1))
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     l_run[1] += l2_run[1];
     l2_run[0] = l2_run[1] = 0.f;
     for (; t + 1 < ntiles; ++t) {           // the 0-5 iterations left before the final tile: guarded DMA, masked row max, full drains
-        body(sA, sB, t, mxA, mxB, std::false_type{});
+        body(sA, sB, t, mxA, mxB);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
