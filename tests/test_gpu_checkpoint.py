@@ -65,7 +65,7 @@ def test_dit_checkpoint_drives_the_hip_path(tmp_path):
     with torch.no_grad():
         t2 = torch.tensor([950.0], device=DEV)
         again = model(x, t2, **kw)["x"].clone()
-        assert getattr(kw["text_states"], "_hv_txt_cache", None) is not None and "emb" in kw["text_states"]._hv_txt_cache
+        assert getattr(kw["text_states"], "_hv_txt_cache", None) is not None and "emb" in kw["text_states"]._hv_txt_cache["rows"][0]
         fresh = build_model(cfg, DEV, seed=3)
         assert torch.equal(again, fresh(x, t2, **kw)["x"])
         x3, kw3, _ = _inputs(cfg, n_valid=5, seed=9)
