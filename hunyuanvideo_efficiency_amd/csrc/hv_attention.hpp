@@ -22,7 +22,13 @@ struct AttnArgs {
     float* part_o;      // [n_splits][n_q][n_heads][128]
     float* part_ml;     // [n_splits][n_q][n_heads][2]
     int partial;        // 1: always leave the unnormalised partial (ring attention merges K/V chunks later), even unsplit
+    // per head: max over the keys of |k|^2 (fp32 bit patterns, written by attn_kmax_kernel; nullable).  With it a wave can bound every
+    // score of a query row by |q'| |k|_max (Cauchy-Schwarz) and, when that bound is within 90 (log2 units) of its first tile's row
+    // max, run the whole key range against the bound as a STATIC maximum: no row max per tile, never a rescale.
+    const unsigned* kmax2;
 };
+constexpr int KMAX_BYTES = 256;      // head of the workspace: 62 heads x 4 bytes + two mode flags (words 62, 63)
+constexpr int KMAX_HEADS = 62;       // word 62: some wave ran against the static bound; word 63: some wave kept the online maximum (tests)
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;

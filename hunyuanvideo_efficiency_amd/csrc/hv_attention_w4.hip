@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     asm volatile("; hv_attention_w4: a[0:255] owned by inline asm" : : : HV_CLOBBER_ALL_AGPRS);
     // O = 0
     static_for<0, 128>([&](auto I) { asm volatile("v_accvgpr_write_b32 a%c0, 0" : : "i"(A_O + decltype(I)::value)); });
-    // Q' = bf16(Q * scale * log2(e)) into a[128:191]
+    // Q' = bf16(Q * scale * log2(e)) into a[128:191]; |q'|^2 per row on the way (of the ROUNDED values the MFMAs will see)
+    float qn2[2] = {0.f, 0.f};
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qrow = min(q0 + qb * 32 + lr, a.n_q - 1);
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
             constexpr int i = decltype(I)::value;      // word i of the query block: fragment ks = i / 4, word j = i % 4
             const uint32_t w = raw[i >> 2][i & 3];
             const uint32_t sc = pack_bf2(bf2f_lo(w) * a.scale_log2e, bf2f_hi(w) * a.scale_log2e);
+            qn2[qb] += bf2f_lo(sc) * bf2f_lo(sc) + bf2f_hi(sc) * bf2f_hi(sc);
             if (qb == 0) acc_write<A_Q + i>(sc);
             else acc_write<A_Q + 32 + i>(sc);
         });
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     float l2_run[2] = {0.f, 0.f};      // second partial row sums of the asm iteration (odd exponentials), folded into l_run at a rescale and at the end
     f32x16 negm[2];
     constexpr float THR = 8.0f;
+    bool static_max = false;      // this wave runs against a static row bound instead of the online maximum (decided after tile 0)
     const int ntiles = (a.n_kv + KVT - 1) / KVT;
 
     // tail mask (last tile) + row max of a score tile pair (relative to m_run)
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     // K(t+1) are in flight into K slots 0 .. PF-1, vk0 points at K(t+1)'s buffer, K(t+2) and V(t+1) have landed or are in flight.
     auto body = [&](f32x16 (&Sc)[2][2], f32x16 (&Sn)[2][2], int t, const float (&mx_c)[2], float (&mx_n)[2]) __attribute__((always_inline)) {
         constexpr bool FULL = false;
-        if (__any(mx_c[0] > THR || mx_c[1] > THR)) raise_max(Sc, mx_c);
+        if (!static_max && __any(mx_c[0] > THR || mx_c[1] > THR)) raise_max(Sc, mx_c);
         // ring positions as LDS byte offsets, rotated by the caller (no division): rb0 = buffer of tile t (V(t); K(t+3) is DMA'd
         // over K(t)), rb2 = buffer of tile t+2 (K(t+2): next S phase; V(t+2) is DMA'd over V(t-1))
         const bool do_k = FULL || (t + 3 < ntiles), do_v = FULL || (t + 2 < ntiles);
@@ -439,6 +442,29 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     // tile 0 fixes the initial max exactly: m_run = rowmax(S(0)), S'(0) = S(0) - m_run (the only explicit subtraction)
     float mxA[2], mxB[2] = {0.f, 0.f};
     tile_max(sA, 0, ntiles == 1, mxA);
+    // STATIC maximum (AttnArgs::kmax2): every score of row r is <= |q'_r| |k|_max (Cauchy-Schwarz; + a margin for the fp32 rounding of
+    // the norms and of the MFMA sums).  If for every row of this wave that bound sits within 90 of the row max of tile 0 - a lower
+    // bound of the row's true max - then P = 2^(S - bound) never exceeds 1 and the row's largest weight is >= 2^-90: nothing
+    // overflows, nothing that matters underflows (fp32 / bf16 keep their relative precision down to 2^-126), so the bound serves as
+    // the maximum for the whole key range: no row max per tile, no rescale.  Otherwise (scores far below the bound: anti-aligned
+    // or tiny first tiles) the wave keeps the online maximum.  Wave-uniform; waves of a workgroup may differ (same barriers / DMA).
+    if (a.kmax2) {
+        const float kn = sqrtf(__uint_as_float(a.kmax2[head]));
+        float bound[2];
+        bool ok = true;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            bound[qb] = sqrtf(half_swap_sum(qn2[qb])) * kn * 1.001f + 1e-3f;
+            ok = ok && (bound[qb] - mxA[qb] <= 90.f);
+        }
+        static_max = __all(ok);
+        // which mode ran, for the tests: plain stores of 1 (many waves write the same word), into the two spare words behind the bounds
+        if (lane == 0) const_cast<unsigned*>(a.kmax2)[static_max ? KMAX_HEADS : KMAX_HEADS + 1] = 1u;
+        if (static_max) {
+            mxA[0] = bound[0];
+            mxA[1] = bound[1];
+        }
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         m_run[qb] = mxA[qb];
@@ -488,6 +514,25 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
         rb1 = rb2;
         rb2 = r;
     };
+    auto iter_static = [&](auto ab_c, int tt) __attribute__((always_inline)) {
+        constexpr bool AB = decltype(ab_c)::value;
+        const u32x4 krs = desc(kbase + (tt + 3) * k_tile_bytes, k_row_bytes), vrs = desc(vbase + (tt + 2) * v_tile_bytes, v_row_bytes);
+        const uint32_t kdst = lds0 + W4_KOFF + rb0 + wave_lds, vdst = lds0 + W4_VOFF + rb2 + wave_lds;
+        if (AB) w4_iter_ab_static(sA, sB, negm, l_run, l2_run, vk0, kread0, vread, koff4, voff4, krs, vrs, kdst, vdst, (uint32_t)rb0, (uint32_t)rb2);
+        else w4_iter_ba_static(sA, sB, negm, l_run, l2_run, vk0, kread0, vread, koff4, voff4, krs, vrs, kdst, vdst, (uint32_t)rb0, (uint32_t)rb2);
+        const int r = rb0;
+        rb0 = rb1;
+        rb1 = rb2;
+        rb2 = r;
+    };
+#ifndef HV_W4_STAMPS
+    if (static_max) {
+        for (; t + 4 < ntiles; t += 2) {
+            iter_static(std::true_type{}, t);
+            iter_static(std::false_type{}, t + 1);
+        }
+    }
+#endif
     for (; t + 4 < ntiles; t += 2) {
         iter_full(std::true_type{}, t);
         iter_full(std::false_type{}, t + 1);
@@ -512,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     }
     // ------------------------------------------------------------------------------------------------ last tile: P(t) and O += V.P only
     {
-        if (__any(mxA[0] > THR || mxA[1] > THR)) raise_max(sA, mxA);
+        if (!static_max && __any(mxA[0] > THR || mxA[1] > THR)) raise_max(sA, mxA);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         set_vv(rb0);
         u32x4 pw[2][4];

@@ -133,12 +133,16 @@ def linear_smallm(x, w, bias=None, silu_in: bool = False, silu_out: bool = False
 _attn_ws = {}
 
 
+ATTN_MIN_WORKSPACE = 256      # hv_attention.hpp KMAX_BYTES: the per-head key-norm bound alone (static-maximum mode of the kernel)
+
+
 def _attn_workspace(n_q, n_kv, n_heads, device):
-    """Scratch for the kernel's optional KV split (load balance of shallow grids); only allocated for shallow grids."""
-    n_wg = ((n_q + 255) // 256) * n_heads
-    if n_wg >= 16 * 256 or n_kv < 64 * 64:
+    """Scratch of hv_attn_fwd_bf16: 256 bytes for the per-head key-norm bound (always, when the key range is long enough for the
+    pre-pass to pay) + the partials of the optional KV split (load balance; only allocated for shallow grids)."""
+    if n_kv < 64 * 64:
         return None
-    need = int(_lib.host("attn_workspace_bytes", n_q, n_kv, n_heads))
+    n_wg = ((n_q + 255) // 256) * n_heads
+    need = ATTN_MIN_WORKSPACE if n_wg >= 16 * 256 else int(_lib.host("attn_workspace_bytes", n_q, n_kv, n_heads))
     key = str(device)
     ws = _attn_ws.get(key)
     if ws is None or ws.numel() < need:

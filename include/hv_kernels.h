@@ -79,15 +79,22 @@ int hv_timestep_embedding_bf16(const float* t, void* out, int n_t, int dim, floa
  * (flash_attn_varlen_func / _flash_attn_forward of modules/attenion.py:107-120,181-207: the caller
  * issues one call per cu_seqlens segment).  q/k/v/o: token-major, head h at column h*128 of each row;
  * strides in elements (so q,k,v may point into one fused QKV buffer and o into a wider concat buffer).
- * workspace (nullable): caller-owned scratch of hv_attn_workspace_bytes(n_q, n_kv, n_heads) bytes.  When given and the
- * launch would be only a few workgroup rounds deep (e.g. 3 heads per rank under Ulysses-8), the key range is split in two
- * halves processed by separate workgroups and merged (log-sum-exp) by a second tiny kernel: shorter makespan, same result
- * up to fp32 rounding.  Without a workspace the single-pass kernel always runs. */
+ * workspace (nullable): caller-owned scratch, used in two steps:
+ *   >= HV_ATTN_MIN_WORKSPACE_BYTES (256) and n_kv >= 4096, n_heads <= 62: a pre-pass leaves max_k |k|^2 per head in its first 256
+ *      bytes and the kernel bounds every score of a query row by |q'| |k|_max; a wave whose rows all have that bound within 90
+ *      (log2 units) of their first tile's row max runs against it as a STATIC maximum (no row max per tile, never a rescale:
+ *      +4 % at S = 119,056), any other wave keeps the online running maximum - same result up to the rounding of P;
+ *   >= hv_attn_workspace_bytes(n_q, n_kv, n_heads) and a launch only a few workgroup rounds deep (e.g. 3 heads per rank under
+ *      Ulysses-8): the key range is split in two halves processed by separate workgroups and merged (log-sum-exp) by a second
+ *      tiny kernel: shorter makespan, same result up to fp32 rounding.
+ * Without a workspace the single-pass kernel with the online maximum always runs.  A workspace must not be shared by launches
+ * that can run concurrently (different streams). */
+#define HV_ATTN_MIN_WORKSPACE_BYTES 256
 int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t stride_q, int64_t stride_k,
                      int64_t stride_v, int64_t stride_o, int n_q, int n_kv, int n_heads, int head_dim,
                      float scale, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
-/* bytes of scratch hv_attn_fwd_bf16 can use for the KV split (returned as int64). */
+/* bytes of scratch hv_attn_fwd_bf16 can use: the 256-byte bound area + the partials of a 2-way KV split (returned as int64). */
 int64_t hv_attn_workspace_bytes(int n_q, int n_kv, int n_heads);
 
 /* Ring attention (hybrid Ulysses x Ring, xfuser `ring_degree > 1`: hyvideo/inference.py:171-175, call site

@@ -98,3 +98,51 @@ def test_run_to_run_identical(ops):
     first = _run(ops, q, k, v, H).clone()
     for _ in range(5):
         assert torch.equal(_run(ops, q, k, v, H), first)
+
+
+def _modes(ops):
+    """(some wave used the static row bound, some wave kept the online maximum) of the last launch that was given a workspace."""
+    ws = ops._attn_ws[str(torch.device(DEV, torch.cuda.current_device()))]
+    torch.cuda.synchronize()
+    w = ws[:256].view(torch.int32).cpu()
+    return bool(w[62]), bool(w[63])
+
+
+def test_static_maximum_mode_and_its_fallback(ops):
+    """Long key ranges (>= 4,096 keys, workspace given) first compute max_k |k| per head; a wave whose rows all have
+    |q'| |k|_max within 90 (log2 units) of their first tile's row max runs against that bound as a static maximum (no row max per
+    tile, never a rescale), the others keep the online maximum.  Both modes and the boundary between them against the oracle:
+      A  ordinary data                                   -> static
+      B  the bound 80-89 above the scores (one large-norm key orthogonal to every query, tuned) -> static, weights ~ 2^-85
+      C  the same key 100x larger                         -> online everywhere (bound - max > 90)
+      D  one query anti-aligned with every key            -> its wave online, the other waves static"""
+    n_q, n_kv, H = 300, 8192, 2
+    dev = torch.device(DEV, torch.cuda.current_device())
+    # A
+    q, k, v = U((n_q, H, 128), "sm.q", 2.0), U((n_kv, H, 128), "sm.k"), U((n_kv, H, 128), "sm.v")
+    _check(ops, q, k, v, H)
+    assert _modes(ops) == (True, False)
+    # B / C: queries live in dims 0..63, one key has a large component in dims 64..127 only: orthogonal to every query (exact zeros)
+    qh = q.clone()
+    qh[:, :, 64:] = 0
+    ks = U((n_kv, H, 128), "sm.ks", 0.3)
+    qn = float(qh.float().norm(dim=-1).max())
+    c = 128 ** -0.5 * 1.4426950408889634
+    big = ks.clone()
+    big[100, :, :64] = 0
+    big[100, :, 64:] = 0
+    big[100, :, 64] = 84.0 / (qn * c)           # |q'|_max |k|_max ~ 84: bound - row max (a few units) in (80, 90) for the longest query
+    _check(ops, qh, big, v, H)
+    assert _modes(ops)[0]
+    huge = big.clone()
+    huge[100, :, 64] = 100 * 84.0 / (qn * c)
+    _check(ops, qh, huge, v, H)
+    assert _modes(ops) == (False, True)
+    # D: query 7 (wave 0 of workgroup 0) points away from every key
+    kd = U((n_kv, H, 128), "sm.kd", 0.2)
+    qd = q.clone()
+    mean_dir = torch.ones(128) / 128 ** 0.5
+    kd = (kd.float() + 3.0 * mean_dir).to(torch.bfloat16)          # every key has a common component of norm 3
+    qd[7] = (-144.0 * mean_dir).to(torch.bfloat16)                 # scores of query 7 ~ -144 * 3 * 0.1275 = -55 (log2 units), bound ~ +69: gap > 90
+    _check(ops, qd, kd, v, H)
+    assert _modes(ops) == (True, True)

@@ -46,11 +46,11 @@ def wait_for(f):    # first MFMA of an even fragment f: f and f+1 landed = all b
     return sum(frag_insts(f + i) for i in range(2, PF))
 
 
-ABL = os.environ.get("HV_W4_ABL", "")      # timing-only ablations (WRONG results): v = no softmax VALU, l = no LDS fragment reads, d = no DMA, w = no lgkmcnt waits
+ABL = os.environ.get("HV_W4_ABL", "")      # timing-only ablations (WRONG results): v = no softmax VALU, l = no LDS fragment reads, d = no DMA, w = no lgkmcnt waits, m = no row max
 STAMPS = os.environ.get("HV_W4_STAMPS") == "1"     # diagnostic build only (never shipped): s_memtime around the barrier's waits
 
 
-def gen_iter(SC, SN):
+def gen_iter(SC, SN, static=False):
     L = []
     A = L.append
     if STAMPS:      # s[90:99] are this build's scratch (clobbered): t0 = iteration start
@@ -148,7 +148,7 @@ def gen_iter(SC, SN):
             kk, qb, j = e >> 4, (e >> 3) & 1, e & 7
             A(f"v_exp_f32 {ex_reg(e)}, {s_reg(SC, qb, kk >> 1, 8 * (kk & 1) + j)}")
         # ---- row max of S'(t+1): two values per gap, chain-complete order
-        if g >= 32:
+        if g >= 32 and not static:
             mi = g - 32
             c = mi >> 3
             qb, kb, r = c & 1, c >> 1, 2 * (mi & 7)
@@ -175,6 +175,8 @@ def gen_iter(SC, SN):
             op = ln.split()[0]
             if "v" in ABL and op in ("v_exp_f32", "v_add_f32", "v_cvt_pk_bf16_f32", "v_max3_f32", "v_max_f32"):
                 return True
+            if "m" in ABL and op in ("v_max3_f32", "v_max_f32"):
+                return True
             if "l" in ABL and (op.startswith("ds_read") or op == "v_xor_b32"):
                 return True
             if "d" in ABL and (op.startswith("buffer_load") or (op == "s_add_u32" and "m0" in ln) or ln.startswith("s_waitcnt vmcnt")):
@@ -183,11 +185,13 @@ def gen_iter(SC, SN):
                 return True
             return False
         L = [ln for ln in L if not drop(ln)]
+        if "m" in ABL:
+            L += [f"v_mov_b32 v{V_MX}, 0", f"v_mov_b32 v{V_MX + 1}, 0"]
     return L
 
 
-def emit_fn(name, SC, SN):
-    body = gen_iter(SC, SN)
+def emit_fn(name, SC, SN, static=False):
+    body = gen_iter(SC, SN, static)
     text = "\n".join(f'        "{ln}\\n\\t"' if not ln.startswith(";") else f'        "{ln}\\n\\t"' for ln in body)
     sc = "sA" if SC == 0 else "sB"
     sn = "sB" if SC == 0 else "sA"
@@ -199,13 +203,16 @@ def emit_fn(name, SC, SN):
     dbg_out = ', [acc_vm] "+s"(acc_vm), [acc_bar] "+s"(acc_bar), [acc_pre] "+s"(acc_pre), [acc_p1] "+s"(acc_p1), [acc_p2] "+s"(acc_p2), [acc_p3] "+s"(acc_p3)' if STAMPS else ""
     if STAMPS:
         clob += [f'"s{i}"' for i in range(90, 99)]
-    return f'''// iteration with S'(t) in {sc} and S'(t+1) produced in {sn}
-__device__ __forceinline__ void {name}(f32x16 (&sA)[2][2], f32x16 (&sB)[2][2], const f32x16 (&negm)[2], float (&l)[2], float (&l2)[2], float (&mx)[2], uint32_t& vk0,
+    mx_arg = "" if static else "float (&mx)[2], "
+    mx_out = "" if static else f'"={{v{V_MX}}}"(mx[0]), "={{v{V_MX + 1}}}"(mx[1]),'
+    kind = "static row bound in -m: no row max of S'(t+1), never a rescale" if static else "online (deferred) running max: row max of S'(t+1) in mx"
+    return f'''// iteration with S'(t) in {sc} and S'(t+1) produced in {sn}; {kind}
+__device__ __forceinline__ void {name}(f32x16 (&sA)[2][2], f32x16 (&sB)[2][2], const f32x16 (&negm)[2], float (&l)[2], float (&l2)[2], {mx_arg}uint32_t& vk0,
                                        uint32_t kread0, uint32_t vread, u32x4 koff, u32x4 voff, u32x4 krs, u32x4 vrs, uint32_t kdst,
                                        uint32_t vdst, uint32_t rb0, uint32_t rb2{dbg_args}) {{
     asm volatile(
 {text}
-        : {tiles(sn, SN, "=")}, "+{{v{V_L}}}"(l[0]), "+{{v{V_L + 1}}}"(l[1]), "+{{v{V_L2}}}"(l2[0]), "+{{v{V_L2 + 1}}}"(l2[1]), "={{v{V_MX}}}"(mx[0]), "={{v{V_MX + 1}}}"(mx[1]),
+        : {tiles(sn, SN, "=")}, "+{{v{V_L}}}"(l[0]), "+{{v{V_L + 1}}}"(l[1]), "+{{v{V_L2}}}"(l2[0]), "+{{v{V_L2 + 1}}}"(l2[1]), {mx_out}
           "+{{v{V_VK0}}}"(vk0){dbg_out}
         : {tiles(sc, SC, "")}, "{{v[{V_NEGM}:{V_NEGM + 15}]}}"(negm[0]), "{{v[{V_NEGM + 16}:{V_NEGM + 31}]}}"(negm[1]),
           "{{v{V_KREAD0}}}"(kread0), "{{v{V_VREAD}}}"(vread), "{{v[{V_KOFF}:{V_KOFF + 3}]}}"(koff), "{{v[{V_VOFF}:{V_VOFF + 3}]}}"(voff),
@@ -220,6 +227,8 @@ def main():
            "// The steady-state iteration of attn_fwd_kernel_w4 as one inline-asm statement per S-buffer role; register map and schedule:\n"
            "// the generator's docstring and the header of hv_attention_w4.hip.\n")
     text = hdr + emit_fn("w4_iter_ab", 0, 64) + "\n" + emit_fn("w4_iter_ba", 64, 0)
+    if not STAMPS:
+        text += "\n" + emit_fn("w4_iter_ab_static", 0, 64, True) + "\n" + emit_fn("w4_iter_ba_static", 64, 0, True)
     return text
 
 
