@@ -28,6 +28,14 @@ LAG = int(os.environ.get("HV_W4_LAG", "1"))       # gaps between a v_exp_f32 and
 EXR = 12                                          # ring of the last exponentials (>= 2 per gap x (LAG + 1) + the pair partner)
 V_NEGM, V_PW, V_EX, V_L, V_MX, V_VK0, V_T0, V_T1, V_VV, V_KREAD0, V_VREAD, V_KOFF, V_VOFF = 128, 160, 222, 200, 202, 204, 205, 220, 206, 210, 211, 212, 216
 V_L2 = 234      # second partial row sum per query block (v234, v235): consecutive adds never hit the same accumulator
+PKADD = os.environ.get("HV_W4_PKADD") == "1"      # experiment: one v_pk_add_f32 per PAIR of exponentials; pairs (v200,v201) = query block 0
+                                                  # (even, odd exponentials), (v234,v235) = query block 1
+
+
+def l_reg(qb, odd):
+    if PKADD:
+        return (V_L if qb == 0 else V_L2) + odd
+    return (V_L2 if odd else V_L) + qb
 
 
 def exps_before(g):
@@ -122,7 +130,13 @@ def gen_iter(SC, SN, static=False):
                     A(f"v_cvt_pk_bf16_f32 v{V_PW + 4 * (4 * qb + kk) + (j >> 1)}, {ex_reg(e - 1)}, {ex_reg(e)}")
             for e in range(exps_before(g - LAG), exps_before(g - LAG + 1)):
                 qb = (e >> 3) & 1
-                acc = (V_L if (e & 1) == 0 else V_L2) + qb
+                if PKADD:
+                    if e & 1:
+                        a0 = l_reg(qb, 0)
+                        e0 = V_EX + ((e - 1) % EXR)
+                        A(f"v_pk_add_f32 v[{a0}:{a0 + 1}], v[{a0}:{a0 + 1}], v[{e0}:{e0 + 1}]")
+                    continue
+                acc = l_reg(qb, e & 1)
                 A(f"v_add_f32 v{acc}, v{acc}, {ex_reg(e)}")
         # ---- fragment reads, PF fragments ahead
         if g % 2 == 0:
@@ -212,7 +226,7 @@ __device__ __forceinline__ void {name}(f32x16 (&sA)[2][2], f32x16 (&sB)[2][2], c
                                        uint32_t vdst, uint32_t rb0, uint32_t rb2{dbg_args}) {{
     asm volatile(
 {text}
-        : {tiles(sn, SN, "=")}, "+{{v{V_L}}}"(l[0]), "+{{v{V_L + 1}}}"(l[1]), "+{{v{V_L2}}}"(l2[0]), "+{{v{V_L2 + 1}}}"(l2[1]), {mx_out}
+        : {tiles(sn, SN, "=")}, "+{{v{l_reg(0, 0)}}}"(l[0]), "+{{v{l_reg(1, 0)}}}"(l[1]), "+{{v{l_reg(0, 1)}}}"(l2[0]), "+{{v{l_reg(1, 1)}}}"(l2[1]), {mx_out}
           "+{{v{V_VK0}}}"(vk0){dbg_out}
         : {tiles(sc, SC, "")}, "{{v[{V_NEGM}:{V_NEGM + 15}]}}"(negm[0]), "{{v[{V_NEGM + 16}:{V_NEGM + 31}]}}"(negm[1]),
           "{{v{V_KREAD0}}}"(kread0), "{{v{V_VREAD}}}"(vread), "{{v[{V_KOFF}:{V_KOFF + 3}]}}"(koff), "{{v[{V_VOFF}:{V_VOFF + 3}]}}"(voff),
