@@ -38,13 +38,20 @@ constexpr int W4_KOFF = 0, W4_VOFF = W4_NBUF * KV_TILE_BYTES;      // LDS bytes:
 constexpr int W4_LDS = 2 * W4_NBUF * KV_TILE_BYTES;               // 96 KiB
 constexpr int A_O = 0, A_Q = 128, A_KF = 192, A_VF = 224;         // accumulator-file map (see header)
 constexpr int RING = 8;       // K and V fragment rings: 8 slots of 4 registers each
-constexpr int PF = 4;         // a fragment is read from LDS PF fragments (2 PF MFMA gaps) ahead of its first MFMA
+#ifndef HV_W4_PF
+#define HV_W4_PF 4
+#endif
+#ifndef HV_W4_WGRP
+#define HV_W4_WGRP 2
+#endif
+constexpr int PF = HV_W4_PF;  // a fragment is read from LDS PF fragments (2 PF MFMA gaps) ahead of its first MFMA
+constexpr int WGRP = HV_W4_WGRP;   // one counted lgkmcnt wait per WGRP fragments (the generator's tables use the same two numbers)
 // LDS instructions issued between fragment f's read and its first use = the reads of fragments f+1 .. f+PF-1 (K: 1 instruction,
 // V: 2; fragments 16..31 of a tile are V, 32.. are the next tile's K)
 __host__ __device__ constexpr int frag_insts(int f) { return (f >= 16 && f < 32) ? 2 : 1; }
 // one wait per PAIR of fragments (a wave alone on its SIMD pays ~4 issue cycles per s_waitcnt even when it is satisfied): the first
 // MFMA of an even fragment f waits until f AND f+1 have landed = all but the reads of f+2 .. f+PF-1
-__host__ __device__ constexpr int wait_for(int f) { int n = 0; for (int i = 2; i < PF; ++i) n += frag_insts(f + i); return n; }
+__host__ __device__ constexpr int wait_for(int f) { int n = 0; for (int i = WGRP; i < PF; ++i) n += frag_insts(f + i); return n; }
 
 // ---------------------------------------------------------------------------------------------------- asm building blocks
 // Every MFMA statement clobbers ALL of a0..a255: hipcc treats the accumulator half as overflow space for long-lived values
@@ -182,11 +189,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
         koff_sw = (uint32_t)((dcp ^ (key & 3)) << 4);
         voff0 = (uint32_t)(key * v_row_bytes + ((dcp ^ ((key & 3) << 2)) << 4));
     }
-    u32x4 koff4, voff4;      // the asm iteration's per-piece voffsets (row step folded in: its buffer loads use soffset 0)
+    // the asm iteration's per-piece voffsets: row step folded in (its buffer loads use soffset 0) and i * 1024 taken OUT - piece i carries
+    // `offset:i*1024`, which the hardware adds to the LDS address (so M0 is written once per tensor and tile) and to the buffer offset
+    u32x4 koff4, voff4;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        koff4[i] = koff_row + (koff_sw ^ (uint32_t)(i << 6)) + (uint32_t)(4 * i * k_row_bytes);
-        voff4[i] = voff0 + (uint32_t)(4 * i * v_row_bytes);
+        koff4[i] = koff_row + (koff_sw ^ (uint32_t)(i << 6)) + (uint32_t)(4 * i * k_row_bytes) - (uint32_t)(i * 1024);
+        voff4[i] = voff0 + (uint32_t)(4 * i * v_row_bytes) - (uint32_t)(i * 1024);
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wave_lds = wave_u * (KEYS_W * 256);
@@ -343,13 +352,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
             if constexpr (G < 32) {
                 constexpr int kb = G >> 4, ks = (G & 15) >> 1, qb = G & 1, f = G >> 1;
                 constexpr int KF = A_KF + 4 * (f % RING), QF = A_Q + 4 * (qb * 8 + ks);
-                constexpr int WAIT = (qb == 0 && (f & 1) == 0) ? wait_for(f) : -1;
+                constexpr int WAIT = (qb == 0 && f % WGRP == 0) ? wait_for(f) : -1;
                 if constexpr (ks == 0) mfma_s_first<KF, QF, WAIT>(Sn[qb][kb], negm[qb]);
                 else mfma_s<KF, QF, WAIT>(Sn[qb][kb]);
             } else {
                 constexpr int j = G - 32, kk = j >> 3, db = (j & 7) >> 1, qb = j & 1, f = 16 + (j >> 1);
                 constexpr int VF = A_VF + 4 * (f % RING), OT = A_O + 16 * (qb * 4 + db);
-                constexpr int WAIT = (qb == 0 && (f & 1) == 0) ? wait_for(f) : -1;
+                constexpr int WAIT = (qb == 0 && f % WGRP == 0) ? wait_for(f) : -1;
                 mfma_pv<OT, VF, WAIT>(pw[qb][kk]);
             }
             // ---- barrier (gap 56): K(t+2) / V(t+1) - this wave's pieces by the counted vmcnt, everyone's by the barrier - have landed

@@ -23,7 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.environ.get("HV_W4_INC_OUT") or os.path.join(ROOT, "hunyuanvideo_efficiency_amd", "csrc", "hv_attention_w4_loop.inc")
 
 A_O, A_Q, A_KF, A_VF = 0, 128, 192, 224
-RING, PF = 8, 4
+RING = 8
+PF = int(os.environ.get("HV_W4_PF", "4"))       # fragments of LDS read-ahead (must match hv_attention_w4.hip)
+WGRP = int(os.environ.get("HV_W4_WGRP", "2"))   # one counted lgkmcnt wait per WGRP fragments (must match hv_attention_w4.hip)
 LAG = int(os.environ.get("HV_W4_LAG", "1"))       # gaps between a v_exp_f32 and the pack / row-sum add that read it
 EXR = 12                                          # ring of the last exponentials (>= 2 per gap x (LAG + 1) + the pair partner)
 V_NEGM, V_PW, V_EX, V_L, V_MX, V_VK0, V_T0, V_T1, V_VV, V_KREAD0, V_VREAD, V_KOFF, V_VOFF = 128, 160, 222, 200, 202, 204, 205, 220, 206, 210, 211, 212, 216
@@ -50,8 +52,8 @@ def frag_insts(f):
     return 2 if 16 <= f < 32 else 1
 
 
-def wait_for(f):    # first MFMA of an even fragment f: f and f+1 landed = all but the reads of f+2 .. f+PF-1 outstanding
-    return sum(frag_insts(f + i) for i in range(2, PF))
+def wait_for(f):    # first MFMA of fragment f (f % WGRP == 0): f .. f+WGRP-1 landed = all but the reads of f+WGRP .. f+PF-1 outstanding
+    return sum(frag_insts(f + i) for i in range(WGRP, PF))
 
 
 ABL = os.environ.get("HV_W4_ABL", "")      # timing-only ablations (WRONG results): v = no softmax VALU, l = no LDS fragment reads, d = no DMA, w = no lgkmcnt waits, m = no row max
@@ -83,15 +85,14 @@ def gen_iter(SC, SN, static=False):
             A("s_sub_u32 s98, s94, s90")
             A(f"s_add_u32 %[acc_p{g // 16}], %[acc_p{g // 16}], s98")
         dma = g < 32 and (g & 3) == 3
-        if dma:
-            i = (g >> 2) & 3
-            A(f"s_add_u32 m0, %[{'kdst' if g < 16 else 'vdst'}], {i * 1024}")
+        if dma and ((g >> 2) & 3) == 0:      # M0 once per tensor: piece i adds i * 1024 through its immediate offset
+            A(f"s_mov_b32 m0, %[{'kdst' if g < 16 else 'vdst'}]")
         # ---- MFMA
         if g < 32:
             f, qb = g >> 1, g & 1
             kb, ks = f >> 3, f & 7
             kf, qf = A_KF + 4 * (f % RING), A_Q + 4 * (qb * 8 + ks)
-            if qb == 0 and f % 2 == 0:
+            if qb == 0 and f % WGRP == 0:
                 A(f"s_waitcnt lgkmcnt({wait_for(f)})")
             c = f"v[{V_NEGM + 16 * qb}:{V_NEGM + 16 * qb + 15}]" if ks == 0 else s_tile(SN, qb, kb)
             A(f"v_mfma_f32_32x32x16_bf16 {s_tile(SN, qb, kb)}, a[{kf}:{kf + 3}], a[{qf}:{qf + 3}], {c}")
@@ -99,7 +100,7 @@ def gen_iter(SC, SN, static=False):
             j = g - 32
             kk, db, qb, f = j >> 3, (j & 7) >> 1, j & 1, 16 + (j >> 1)
             vf, ot = A_VF + 4 * (f % RING), A_O + 16 * (qb * 4 + db)
-            if qb == 0 and f % 2 == 0:
+            if qb == 0 and f % WGRP == 0:
                 A(f"s_waitcnt lgkmcnt({wait_for(f)})")
             pw = V_PW + 4 * (4 * qb + kk)
             A(f"v_mfma_f32_32x32x16_bf16 a[{ot}:{ot + 15}], a[{vf}:{vf + 3}], v[{pw}:{pw + 3}], a[{ot}:{ot + 15}]")
@@ -181,9 +182,9 @@ def gen_iter(SC, SN, static=False):
         if dma:
             i = (g >> 2) & 3
             if g < 16:
-                A(f"buffer_load_dwordx4 v{V_KOFF + i}, %[krs], 0 offen lds")
+                A(f"buffer_load_dwordx4 v{V_KOFF + i}, %[krs], 0 offen{f' offset:{i * 1024}' if i else ''} lds")
             else:
-                A(f"buffer_load_dwordx4 v{V_VOFF + i}, %[vrs], 0 offen lds")
+                A(f"buffer_load_dwordx4 v{V_VOFF + i}, %[vrs], 0 offen{f' offset:{i * 1024}' if i else ''} lds")
     if ABL:
         def drop(ln):
             op = ln.split()[0]
