@@ -16,10 +16,13 @@
 //   a[192:223]  K fragment ring, 8 slots of 4 (ds_read_b128 straight into the accumulator file)
 //   a[224:255]  V^T fragment ring, 8 slots of 4 (two ds_read_b64_tr_b16 each)
 //   v: S'(t) and S'(t+1) 2 x 64, -m (C operand of the S chains) 32, packed P 32, addresses / statistics ~ 30   (compiler-allocated)
-// LDS: K and V tile rings, THREE deep each (96 KiB; one workgroup per CU): the DMA of a tile never targets a buffer that is being
+// LDS: K and V tile rings, FOUR deep each (128 KiB; one workgroup per CU): the DMA of a tile never targets a buffer that is being
 // read in the same iteration, so its eight 1-KiB pieces per wave are spread over the S phase (one every fourth MFMA gap) instead
 // of sitting in a burst behind the barrier; K(t+3) and V(t+2) are issued during iteration t and retired by the COUNTED
-// `s_waitcnt vmcnt(8)` of iteration t+1's barrier.
+// `s_waitcnt vmcnt(8)` of iteration t+1's barrier.  Tile t lives in ring buffer t & 3 and the steady-state loop is unrolled x4, so
+// every buffer offset is an IMMEDIATE of its ds_read / of the DMA's M0 write and the fragment address registers (K: one per k-step
+// with the swizzle XOR folded in, V: one per d-block) are set once per kernel - no address arithmetic in the loop at all (a
+// three-deep ring rotated at run time cost 17 VALU instructions per tile: one XOR per K fragment read + the base updates).
 // Iteration t (64 MFMA gaps, one scheduling fence per gap; consumes S'(t), produces S'(t+1)):
 //   gaps  0-31  S'(t+1) chains, K fragment f = gap/2 for both query blocks | 40 of the 64 exp2 of P(t) (5 per 4 gaps), packs, row sums
 //   gaps 32-63  O += V(t).P(t), V fragment per two gaps                    | the other 24 exp2 (gaps 32-55), row max of S'(t+1)
@@ -33,9 +36,9 @@ using namespace hv_attn;
 
 namespace {
 
-constexpr int W4_WAVES = 4, W4_QTILE = 256, W4_NBUF = 3;
-constexpr int W4_KOFF = 0, W4_VOFF = W4_NBUF * KV_TILE_BYTES;      // LDS bytes: [K0 | K1 | K2 | V0 | V1 | V2]
-constexpr int W4_LDS = 2 * W4_NBUF * KV_TILE_BYTES;               // 96 KiB
+constexpr int W4_WAVES = 4, W4_QTILE = 256, W4_NBUF = 4;
+constexpr int W4_KOFF = 0, W4_VOFF = W4_NBUF * KV_TILE_BYTES;      // LDS bytes: [K0 | K1 | K2 | K3 | V0 | V1 | V2 | V3]
+constexpr int W4_LDS = 2 * W4_NBUF * KV_TILE_BYTES;               // 128 KiB
 constexpr int A_O = 0, A_Q = 128, A_KF = 192, A_VF = 224;         // accumulator-file map (see header)
 constexpr int RING = 8;       // K and V fragment rings: 8 slots of 4 registers each
 #ifndef HV_W4_PF
@@ -231,7 +234,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
         const int chunk16 = ((vG & 1) * 16 + 4 * vp) >> 3;
         vread = lds0 + W4_VOFF + key * 256 + ((chunk16 ^ ((key & 3) << 2)) << 4) + (vp & 1) * 8;
     }
-    // per-tile fragment addresses: K fragment ks at (vk0 ^ (ks << 5)), vk0 = kread0 + K buffer (one XOR per read, no address table);
+    // the generated steady-state iterations address every ring buffer through immediates: their fragment address registers are static
+    u32x4 vks_lo, vks_hi, vv4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        vks_lo[i] = kread0 ^ (uint32_t)(i << 5);
+        vks_hi[i] = kread0 ^ (uint32_t)((i + 4) << 5);
+        vv4[i] = vread ^ (uint32_t)(i << 6);
+    }
+    // (the tail iterations below keep run-time buffer offsets:) per-tile fragment addresses: K fragment ks at (vk0 ^ (ks << 5)), vk0 = kread0 + K buffer (one XOR per read, no address table);
     // V fragment db at vv[db] = (vread + V buffer) ^ (db << 6)
     uint32_t vk0, vv[4];
     auto set_vk = [&](int buf_bytes) { vk0 = kread0 + buf_bytes; };
@@ -241,7 +252,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
         for (int db = 0; db < 4; ++db) vv[db] = b ^ (db << 6);
     };
 
-    int rb0 = 0, rb1 = KV_TILE_BYTES, rb2 = 2 * KV_TILE_BYTES;      // LDS byte offsets of the buffers of tiles t, t+1, t+2 (rotated per iteration)
     // ---- softmax state per query block
     float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
     float l2_run[2] = {0.f, 0.f};      // second partial row sums of the asm iteration (odd exponentials), folded into l_run at a rescale and at the end
@@ -315,8 +325,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     auto body = [&](f32x16 (&Sc)[2][2], f32x16 (&Sn)[2][2], int t, const float (&mx_c)[2], float (&mx_n)[2]) __attribute__((always_inline)) {
         constexpr bool FULL = false;
         if (!static_max && __any(mx_c[0] > THR || mx_c[1] > THR)) raise_max(Sc, mx_c);
-        // ring positions as LDS byte offsets, rotated by the caller (no division): rb0 = buffer of tile t (V(t); K(t+3) is DMA'd
-        // over K(t)), rb2 = buffer of tile t+2 (K(t+2): next S phase; V(t+2) is DMA'd over V(t-1))
+        // ring positions as LDS byte offsets: tile u lives in buffer u & 3
+        const int rb0 = (t & 3) * KV_TILE_BYTES, rb2 = ((t + 2) & 3) * KV_TILE_BYTES, rb3 = ((t + 3) & 3) * KV_TILE_BYTES;
         const bool do_k = FULL || (t + 3 < ntiles), do_v = FULL || (t + 2 < ntiles);
         u32x4 pw[2][4];                       // packed P: [qb][k-step]
         float ex[64];                         // this tile's exponentials (compile-time indices: each lives for about two gaps)
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
             if constexpr (G < 32 && (G & 3) == 3) {
                 constexpr int i = (G >> 2) & 3;
                 if constexpr (G < 16) {
-                    if (do_k) dma_k_piece(krs, W4_KOFF + rb0, i);
+                    if (do_k) dma_k_piece(krs, W4_KOFF + rb3, i);
                 } else {
                     if (do_v) dma_v_piece(vrs, W4_VOFF + rb2, i);
                 }
@@ -421,11 +431,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
         } else {
             tile_max(Sn, t + 1, t + 2 == ntiles, mx_n);
         }
-        // rotate the ring: tile t+1's buffer becomes "rb0"
-        const int r = rb0;
-        rb0 = rb1;
-        rb1 = rb2;
-        rb2 = r;
     };
 
     // ------------------------------------------------------------------------------------------------ prologue
@@ -506,8 +511,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     uint32_t dbg_vm = 0, dbg_bar = 0, dbg_pre = 0, dbg_p1 = 0, dbg_p2 = 0, dbg_p3 = 0;
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    auto iter_full = [&](auto ab_c, int tt) __attribute__((always_inline)) {
-        constexpr bool AB = decltype(ab_c)::value;
+    const uint32_t ldsw = lds0 + wave_lds;
+    auto iter_full = [&](auto j_c, int tt) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_c)::value;          // tt = J (mod 4): S'(tt) lives in sA for even J
+        constexpr bool AB = (J & 1) == 0;
         float (&mc)[2] = AB ? mxA : mxB;
         float (&mn)[2] = AB ? mxB : mxA;
         if (__any(mc[0] > THR || mc[1] > THR)) {
@@ -515,36 +522,34 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
             else raise_max(sB, mc);
         }
         const u32x4 krs = desc(kbase + (tt + 3) * k_tile_bytes, k_row_bytes), vrs = desc(vbase + (tt + 2) * v_tile_bytes, v_row_bytes);
-        const uint32_t kdst = lds0 + W4_KOFF + rb0 + wave_lds, vdst = lds0 + W4_VOFF + rb2 + wave_lds;
-        if (AB) w4_iter_ab(sA, sB, negm, l_run, l2_run, mn, vk0, kread0, vread, koff4, voff4, krs, vrs, kdst, vdst, (uint32_t)rb0, (uint32_t)rb2 HV_W4_DBG_ARGS);
-        else w4_iter_ba(sA, sB, negm, l_run, l2_run, mn, vk0, kread0, vread, koff4, voff4, krs, vrs, kdst, vdst, (uint32_t)rb0, (uint32_t)rb2 HV_W4_DBG_ARGS);
-        const int r = rb0;
-        rb0 = rb1;
-        rb1 = rb2;
-        rb2 = r;
-    };
-    auto iter_static = [&](auto ab_c, int tt) __attribute__((always_inline)) {
-        constexpr bool AB = decltype(ab_c)::value;
-        const u32x4 krs = desc(kbase + (tt + 3) * k_tile_bytes, k_row_bytes), vrs = desc(vbase + (tt + 2) * v_tile_bytes, v_row_bytes);
-        const uint32_t kdst = lds0 + W4_KOFF + rb0 + wave_lds, vdst = lds0 + W4_VOFF + rb2 + wave_lds;
-        if (AB) w4_iter_ab_static(sA, sB, negm, l_run, l2_run, vk0, kread0, vread, koff4, voff4, krs, vrs, kdst, vdst, (uint32_t)rb0, (uint32_t)rb2);
-        else w4_iter_ba_static(sA, sB, negm, l_run, l2_run, vk0, kread0, vread, koff4, voff4, krs, vrs, kdst, vdst, (uint32_t)rb0, (uint32_t)rb2);
-        const int r = rb0;
-        rb0 = rb1;
-        rb1 = rb2;
-        rb2 = r;
+        if constexpr (J == 0) w4_iter_0(sA, sB, negm, l_run, l2_run, mn, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw HV_W4_DBG_ARGS);
+        else if constexpr (J == 1) w4_iter_1(sA, sB, negm, l_run, l2_run, mn, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw HV_W4_DBG_ARGS);
+        else if constexpr (J == 2) w4_iter_2(sA, sB, negm, l_run, l2_run, mn, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw HV_W4_DBG_ARGS);
+        else w4_iter_3(sA, sB, negm, l_run, l2_run, mn, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw HV_W4_DBG_ARGS);
     };
 #ifndef HV_W4_STAMPS
+    auto iter_static = [&](auto j_c, int tt) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_c)::value;
+        const u32x4 krs = desc(kbase + (tt + 3) * k_tile_bytes, k_row_bytes), vrs = desc(vbase + (tt + 2) * v_tile_bytes, v_row_bytes);
+        if constexpr (J == 0) w4_iter_0_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw);
+        else if constexpr (J == 1) w4_iter_1_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw);
+        else if constexpr (J == 2) w4_iter_2_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw);
+        else w4_iter_3_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw);
+    };
     if (static_max) {
-        for (; t + 4 < ntiles; t += 2) {
-            iter_static(std::true_type{}, t);
-            iter_static(std::false_type{}, t + 1);
+        for (; t + 6 < ntiles; t += 4) {         // all four FULL: K((t+3)+3) exists
+            iter_static(std::integral_constant<int, 0>{}, t);
+            iter_static(std::integral_constant<int, 1>{}, t + 1);
+            iter_static(std::integral_constant<int, 2>{}, t + 2);
+            iter_static(std::integral_constant<int, 3>{}, t + 3);
         }
     }
 #endif
-    for (; t + 4 < ntiles; t += 2) {
-        iter_full(std::true_type{}, t);
-        iter_full(std::false_type{}, t + 1);
+    for (; t + 6 < ntiles; t += 4) {
+        iter_full(std::integral_constant<int, 0>{}, t);
+        iter_full(std::integral_constant<int, 1>{}, t + 1);
+        iter_full(std::integral_constant<int, 2>{}, t + 2);
+        iter_full(std::integral_constant<int, 3>{}, t + 3);
     }
 #ifdef HV_W4_STAMPS
     if (blockIdx.x == 300 && wave_u == 1 && lane == 0) {       // a mid-launch workgroup (every CU busy), one wave
@@ -552,6 +557,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
         g_w4_dbg[0] = dbg_vm; g_w4_dbg[1] = dbg_bar; g_w4_dbg[2] = dbg_pre; g_w4_dbg[3] = (unsigned)(dbg_t1 - dbg_t0); g_w4_dbg[4] = (unsigned)t; g_w4_dbg[5] = dbg_p1; g_w4_dbg[6] = dbg_p2; g_w4_dbg[7] = dbg_p3;
     }
 #endif
+    // the tail iterations keep run-time ring offsets: point vk0 at K(t+1)'s buffer (its first PF fragments are already in flight)
+    set_vk(((t + 1) & 3) * KV_TILE_BYTES);
     l_run[0] += l2_run[0];
     l_run[1] += l2_run[1];
     l2_run[0] = l2_run[1] = 0.f;
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
     {
         if (!static_max && __any(mxA[0] > THR || mxA[1] > THR)) raise_max(sA, mxA);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        set_vv(rb0);
+        set_vv((t & 3) * KV_TILE_BYTES);
         u32x4 pw[2][4];
         float ls[2] = {0.f, 0.f};
 #pragma unroll

@@ -87,7 +87,7 @@ def test_generated_attention_iteration_is_up_to_date_and_consistent():
     spec.loader.exec_module(g)
     assert not g.STAMPS and not g.ABL
     assert open(g.OUT).read() == g.main(), "run python tools/gen_attn_w4_asm.py"
-    body = g.gen_iter(0, 64)
+    body = g.gen_iter(0)
     gaps, cur = [], None
     for ln in body:
         if ln.startswith("; ---- gap"):

@@ -12,8 +12,9 @@ Register map (arch VGPRs pinned by "{v[..]}" constraints, accumulator registers 
   v[128:159] -m, the C operand of the S chains (qb 0 | 1)
   v[160:191] packed P: (qb, k-step kk) at 160 + 4 (4 qb + kk)
   v[192:199] ring of the last 8 exponentials     v200 v201 row sums l[qb]     v202 v203 row max of S'(t+1) [qb] (lane-local)
-  v204 K fragment base of the tile being read    v205 v220 XOR temporaries     v[206:209] V fragment bases (db 0..3)
-  v210 kread0   v211 vread   v[212:215] K DMA offsets (piece 0..3)   v[216:219] V DMA offsets
+  v[206:209] V fragment addresses (db 0..3) and v[236:243] K fragment addresses (ks 0..7): STATIC per kernel - the four-deep K / V tile
+  rings are walked by a x4 unrolled loop, so every ring buffer is a compile-time immediate of the ds_read / the DMA's M0
+  v[212:215] K DMA offsets (piece 0..3)   v[216:219] V DMA offsets
   a[0:127] O   a[128:191] Q'   a[192:223] K fragment ring (8 x 4)   a[224:255] V fragment ring (8 x 4)
 Schedule per iteration t (64 MFMA gaps): see hv_attention_w4.hip header; the tables here are the single source of it.
 """
@@ -28,7 +29,9 @@ PF = int(os.environ.get("HV_W4_PF", "4"))       # fragments of LDS read-ahead (m
 WGRP = int(os.environ.get("HV_W4_WGRP", "2"))   # one counted lgkmcnt wait per WGRP fragments (must match hv_attention_w4.hip)
 LAG = int(os.environ.get("HV_W4_LAG", "1"))       # gaps between a v_exp_f32 and the pack / row-sum add that read it
 EXR = 12                                          # ring of the last exponentials (>= 2 per gap x (LAG + 1) + the pair partner)
-V_NEGM, V_PW, V_EX, V_L, V_MX, V_VK0, V_T0, V_T1, V_VV, V_KREAD0, V_VREAD, V_KOFF, V_VOFF = 128, 160, 222, 200, 202, 204, 205, 220, 206, 210, 211, 212, 216
+V_NEGM, V_PW, V_EX, V_L, V_MX, V_VV, V_KOFF, V_VOFF, V_VKS = 128, 160, 222, 200, 202, 206, 212, 216, 236
+NBUF, TILE_BYTES = 4, 16384
+LDS_KOFF, LDS_VOFF = 0, NBUF * TILE_BYTES      # LDS bytes: [K0 K1 K2 K3 | V0 V1 V2 V3]
 V_L2 = 234      # second partial row sum per query block (v234, v235): consecutive adds never hit the same accumulator
 PKADD = os.environ.get("HV_W4_PKADD") == "1"      # experiment: one v_pk_add_f32 per PAIR of exponentials; pairs (v200,v201) = query block 0
                                                   # (even, odd exponentials), (v234,v235) = query block 1
@@ -60,7 +63,12 @@ ABL = os.environ.get("HV_W4_ABL", "")      # timing-only ablations (WRONG result
 STAMPS = os.environ.get("HV_W4_STAMPS") == "1"     # diagnostic build only (never shipped): s_memtime around the barrier's waits
 
 
-def gen_iter(SC, SN, static=False):
+def gen_iter(j, static=False):
+    """iteration t with t = j (mod 4): S'(t) in S_A for even j; K(t+1) in ring buffer (j+1)&3, V(t) in j&3, K(t+2) (its first PF
+    fragments are read at the end) in (j+2)&3; DMA targets K(t+3) -> (j+3)&3, V(t+2) -> (j+2)&3"""
+    SC, SN = (0, 64) if j % 2 == 0 else (64, 0)
+    KB1, KB2, VB = ((j + 1) & 3) * TILE_BYTES, ((j + 2) & 3) * TILE_BYTES, (j & 3) * TILE_BYTES
+    KD, VD = LDS_KOFF + ((j + 3) & 3) * TILE_BYTES, LDS_VOFF + ((j + 2) & 3) * TILE_BYTES
     L = []
     A = L.append
     if STAMPS:      # s[90:99] are this build's scratch (clobbered): t0 = iteration start
@@ -76,7 +84,6 @@ def gen_iter(SC, SN, static=False):
     def ex_reg(e):
         return f"v{V_EX + (e % EXR)}"
 
-    ktmp = [V_T0, V_T1]
     for g in range(64):
         A(f"; ---- gap {g}")
         if STAMPS and g in (16, 32, 48):      # phase stamps (each drains the LDS queue: timing of this build only)
@@ -86,7 +93,7 @@ def gen_iter(SC, SN, static=False):
             A(f"s_add_u32 %[acc_p{g // 16}], %[acc_p{g // 16}], s98")
         dma = g < 32 and (g & 3) == 3
         if dma and ((g >> 2) & 3) == 0:      # M0 once per tensor: piece i adds i * 1024 through its immediate offset
-            A(f"s_mov_b32 m0, %[{'kdst' if g < 16 else 'vdst'}]")
+            A(f"s_add_u32 m0, %[ldsw], {KD if g < 16 else VD}")
         # ---- MFMA
         if g < 32:
             f, qb = g >> 1, g & 1
@@ -146,18 +153,13 @@ def gen_iter(SC, SN, static=False):
                 fk = f2 if f2 < 16 else f2 - 32
                 slot = A_KF + 4 * (f2 % RING)
                 ks, kb = fk & 7, fk >> 3
-                addr = f"v{V_VK0}"
-                if ks:
-                    t = ktmp[(f2 >> 0) & 1]
-                    A(f"v_xor_b32 v{t}, {ks << 5:#x}, v{V_VK0}")
-                    addr = f"v{t}"
-                A(f"ds_read_b128 a[{slot}:{slot + 3}], {addr} offset:{kb * 8192}")
+                A(f"ds_read_b128 a[{slot}:{slot + 3}], v{V_VKS + ks} offset:{(KB1 if f2 < 16 else KB2) + kb * 8192}")
             else:
                 j2 = f2 - 16
                 kk2, db2 = j2 >> 2, j2 & 3
                 slot = A_VF + 4 * (f2 % RING)
-                A(f"ds_read_b64_tr_b16 a[{slot}:{slot + 1}], v{V_VV + db2} offset:{kk2 * 4096}")
-                A(f"ds_read_b64_tr_b16 a[{slot + 2}:{slot + 3}], v{V_VV + db2} offset:{kk2 * 4096 + 2048}")
+                A(f"ds_read_b64_tr_b16 a[{slot}:{slot + 1}], v{V_VV + db2} offset:{VB + kk2 * 4096}")
+                A(f"ds_read_b64_tr_b16 a[{slot + 2}:{slot + 3}], v{V_VV + db2} offset:{VB + kk2 * 4096 + 2048}")
         # ---- exponentials of P(t)
         for e in range(exps_before(g), exps_before(g + 1)):
             kk, qb, j = e >> 4, (e >> 3) & 1, e & 7
@@ -171,13 +173,6 @@ def gen_iter(SC, SN, static=False):
                 A(f"v_max_f32 v{V_MX + qb}, {s_reg(SN, qb, kb, r)}, {s_reg(SN, qb, kb, r + 1)}")
             else:
                 A(f"v_max3_f32 v{V_MX + qb}, v{V_MX + qb}, {s_reg(SN, qb, kb, r)}, {s_reg(SN, qb, kb, r + 1)}")
-        # ---- per-tile address registers: V(t) bases before its first read (gap 24), K(t+2) base after the last K(t+1) read (gap 22)
-        if g == 12:
-            A(f"v_add_u32 v{V_VV}, %[rb0], v{V_VREAD}")
-        if g in (13, 14, 15):
-            A(f"v_xor_b32 v{V_VV + g - 12}, {(g - 12) << 6:#x}, v{V_VV}")
-        if g == 44:
-            A(f"v_add_u32 v{V_VK0}, %[rb2], v{V_KREAD0}")
         # ---- DMA piece (K(t+3) at gaps 3..15, V(t+2) at gaps 19..31); M0 was written at the top of the gap
         if dma:
             i = (g >> 2) & 3
@@ -205,33 +200,32 @@ def gen_iter(SC, SN, static=False):
     return L
 
 
-def emit_fn(name, SC, SN, static=False):
-    body = gen_iter(SC, SN, static)
-    text = "\n".join(f'        "{ln}\\n\\t"' if not ln.startswith(";") else f'        "{ln}\\n\\t"' for ln in body)
+def emit_fn(name, j, static=False):
+    body = gen_iter(j, static)
+    SC, SN = (0, 64) if j % 2 == 0 else (64, 0)
+    text = "\n".join(f'        "{ln}\\n\\t"' for ln in body)
     sc = "sA" if SC == 0 else "sB"
     sn = "sB" if SC == 0 else "sA"
 
     def tiles(var, base, pre):
         return ", ".join(f'"{pre}{{v[{base + 16 * (2 * qb + kb)}:{base + 16 * (2 * qb + kb) + 15}]}}"({var}[{qb}][{kb}])' for qb in range(2) for kb in range(2))
-    clob = [f'"v{i}"' for i in list(range(V_PW, V_PW + 32)) + list(range(V_EX, V_EX + EXR)) + [V_T0, V_T1] + list(range(V_VV, V_VV + 4))]
+    clob = [f'"v{i}"' for i in list(range(V_PW, V_PW + 32)) + list(range(V_EX, V_EX + EXR))]
     dbg_args = ", uint32_t& acc_vm, uint32_t& acc_bar, uint32_t& acc_pre, uint32_t& acc_p1, uint32_t& acc_p2, uint32_t& acc_p3" if STAMPS else ""
     dbg_out = ', [acc_vm] "+s"(acc_vm), [acc_bar] "+s"(acc_bar), [acc_pre] "+s"(acc_pre), [acc_p1] "+s"(acc_p1), [acc_p2] "+s"(acc_p2), [acc_p3] "+s"(acc_p3)' if STAMPS else ""
     if STAMPS:
         clob += [f'"s{i}"' for i in range(90, 99)]
     mx_arg = "" if static else "float (&mx)[2], "
-    mx_out = "" if static else f'"={{v{V_MX}}}"(mx[0]), "={{v{V_MX + 1}}}"(mx[1]),'
+    mx_out = "" if static else f', "={{v{V_MX}}}"(mx[0]), "={{v{V_MX + 1}}}"(mx[1])'
     kind = "static row bound in -m: no row max of S'(t+1), never a rescale" if static else "online (deferred) running max: row max of S'(t+1) in mx"
-    return f'''// iteration with S'(t) in {sc} and S'(t+1) produced in {sn}; {kind}
-__device__ __forceinline__ void {name}(f32x16 (&sA)[2][2], f32x16 (&sB)[2][2], const f32x16 (&negm)[2], float (&l)[2], float (&l2)[2], {mx_arg}uint32_t& vk0,
-                                       uint32_t kread0, uint32_t vread, u32x4 koff, u32x4 voff, u32x4 krs, u32x4 vrs, uint32_t kdst,
-                                       uint32_t vdst, uint32_t rb0, uint32_t rb2{dbg_args}) {{
+    return f'''// iteration t = {j} (mod 4): S'(t) in {sc}, S'(t+1) produced in {sn}; K(t+1) in ring buffer {(j + 1) & 3}, V(t) in {j & 3}; {kind}
+__device__ __forceinline__ void {name}(f32x16 (&sA)[2][2], f32x16 (&sB)[2][2], const f32x16 (&negm)[2], float (&l)[2], float (&l2)[2], {mx_arg}
+                                       u32x4 vks_lo, u32x4 vks_hi, u32x4 vv, u32x4 koff, u32x4 voff, u32x4 krs, u32x4 vrs, uint32_t ldsw{dbg_args}) {{
     asm volatile(
 {text}
-        : {tiles(sn, SN, "=")}, "+{{v{l_reg(0, 0)}}}"(l[0]), "+{{v{l_reg(1, 0)}}}"(l[1]), "+{{v{l_reg(0, 1)}}}"(l2[0]), "+{{v{l_reg(1, 1)}}}"(l2[1]), {mx_out}
-          "+{{v{V_VK0}}}"(vk0){dbg_out}
+        : {tiles(sn, SN, "=")}, "+{{v{l_reg(0, 0)}}}"(l[0]), "+{{v{l_reg(1, 0)}}}"(l[1]), "+{{v{l_reg(0, 1)}}}"(l2[0]), "+{{v{l_reg(1, 1)}}}"(l2[1]){mx_out}{dbg_out}
         : {tiles(sc, SC, "")}, "{{v[{V_NEGM}:{V_NEGM + 15}]}}"(negm[0]), "{{v[{V_NEGM + 16}:{V_NEGM + 31}]}}"(negm[1]),
-          "{{v{V_KREAD0}}}"(kread0), "{{v{V_VREAD}}}"(vread), "{{v[{V_KOFF}:{V_KOFF + 3}]}}"(koff), "{{v[{V_VOFF}:{V_VOFF + 3}]}}"(voff),
-          [krs] "s"(krs), [vrs] "s"(vrs), [kdst] "s"(kdst), [vdst] "s"(vdst), [rb0] "s"(rb0), [rb2] "s"(rb2)
+          "{{v[{V_VKS}:{V_VKS + 3}]}}"(vks_lo), "{{v[{V_VKS + 4}:{V_VKS + 7}]}}"(vks_hi), "{{v[{V_VV}:{V_VV + 3}]}}"(vv),
+          "{{v[{V_KOFF}:{V_KOFF + 3}]}}"(koff), "{{v[{V_VOFF}:{V_VOFF + 3}]}}"(voff), [krs] "s"(krs), [vrs] "s"(vrs), [ldsw] "s"(ldsw)
         : {", ".join(clob)}, "scc", "memory", HV_CLOBBER_ALL_AGPRS);
 }}
 '''
@@ -239,11 +233,12 @@ __device__ __forceinline__ void {name}(f32x16 (&sA)[2][2], f32x16 (&sB)[2][2], c
 
 def main():
     hdr = ("// GENERATED by tools/gen_attn_w4_asm.py - do not edit by hand (tests/test_capi_cpu.py checks it is up to date).\n"
-           "// The steady-state iteration of attn_fwd_kernel_w4 as one inline-asm statement per S-buffer role; register map and schedule:\n"
+           "// The steady-state iteration of attn_fwd_kernel_w4 as one inline-asm statement per position in the x4 unrolled loop (S-buffer role and\n"
+           "// ring buffers are compile-time), in two kinds (online running max / static row bound); register map and schedule:\n"
            "// the generator's docstring and the header of hv_attention_w4.hip.\n")
-    text = hdr + emit_fn("w4_iter_ab", 0, 64) + "\n" + emit_fn("w4_iter_ba", 64, 0)
+    text = hdr + "\n".join(emit_fn(f"w4_iter_{j}", j) for j in range(4))
     if not STAMPS:
-        text += "\n" + emit_fn("w4_iter_ab_static", 0, 64, True) + "\n" + emit_fn("w4_iter_ba_static", 64, 0, True)
+        text += "\n" + "\n".join(emit_fn(f"w4_iter_{j}_static", j, True) for j in range(4))
     return text
 
 
