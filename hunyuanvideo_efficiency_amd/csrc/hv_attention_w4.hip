@@ -527,14 +527,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
         else if constexpr (J == 2) w4_iter_2(sA, sB, negm, l_run, l2_run, mn, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw HV_W4_DBG_ARGS);
         else w4_iter_3(sA, sB, negm, l_run, l2_run, mn, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw HV_W4_DBG_ARGS);
     };
-#ifndef HV_W4_STAMPS
     auto iter_static = [&](auto j_c, int tt) __attribute__((always_inline)) {
         constexpr int J = decltype(j_c)::value;
         const u32x4 krs = desc(kbase + (tt + 3) * k_tile_bytes, k_row_bytes), vrs = desc(vbase + (tt + 2) * v_tile_bytes, v_row_bytes);
-        if constexpr (J == 0) w4_iter_0_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw);
-        else if constexpr (J == 1) w4_iter_1_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw);
-        else if constexpr (J == 2) w4_iter_2_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw);
-        else w4_iter_3_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw);
+        if constexpr (J == 0) w4_iter_0_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw HV_W4_DBG_ARGS);
+        else if constexpr (J == 1) w4_iter_1_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw HV_W4_DBG_ARGS);
+        else if constexpr (J == 2) w4_iter_2_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw HV_W4_DBG_ARGS);
+        else w4_iter_3_static(sA, sB, negm, l_run, l2_run, vks_lo, vks_hi, vv4, koff4, voff4, krs, vrs, ldsw HV_W4_DBG_ARGS);
     };
     if (static_max) {
         for (; t + 6 < ntiles; t += 4) {         // all four FULL: K((t+3)+3) exists
@@ -544,7 +543,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_w4(AttnArgs a) {
             iter_static(std::integral_constant<int, 3>{}, t + 3);
         }
     }
-#endif
     for (; t + 6 < ntiles; t += 4) {
         iter_full(std::integral_constant<int, 0>{}, t);
         iter_full(std::integral_constant<int, 1>{}, t + 1);

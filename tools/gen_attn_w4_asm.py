@@ -52,14 +52,14 @@ def exps_before(g):
 
 
 def frag_insts(f):
-    return 2 if 16 <= f < 32 else 1
+    return 2 if (16 <= f < 32 and "H" not in ABL) else 1
 
 
 def wait_for(f):    # first MFMA of fragment f (f % WGRP == 0): f .. f+WGRP-1 landed = all but the reads of f+WGRP .. f+PF-1 outstanding
     return sum(frag_insts(f + i) for i in range(WGRP, PF))
 
 
-ABL = os.environ.get("HV_W4_ABL", "")      # timing-only ablations (WRONG results): v = no softmax VALU, l = no LDS fragment reads, d = no DMA, w = no lgkmcnt waits, m = no row max
+ABL = os.environ.get("HV_W4_ABL", "")      # timing-only ablations (WRONG results): v = no softmax VALU, l = no LDS fragment reads, d = no DMA, w = no lgkmcnt waits, m = no row max, H = one ds_read_b128 per V fragment
 STAMPS = os.environ.get("HV_W4_STAMPS") == "1"     # diagnostic build only (never shipped): s_memtime around the barrier's waits
 
 
@@ -158,8 +158,11 @@ def gen_iter(j, static=False):
                 j2 = f2 - 16
                 kk2, db2 = j2 >> 2, j2 & 3
                 slot = A_VF + 4 * (f2 % RING)
-                A(f"ds_read_b64_tr_b16 a[{slot}:{slot + 1}], v{V_VV + db2} offset:{VB + kk2 * 4096}")
-                A(f"ds_read_b64_tr_b16 a[{slot + 2}:{slot + 3}], v{V_VV + db2} offset:{VB + kk2 * 4096 + 2048}")
+                if "H" in ABL:      # timing only: what a V pre-transposed in HBM would issue - ONE 16-byte read per fragment (same bytes)
+                    A(f"ds_read_b128 a[{slot}:{slot + 3}], v{V_VKS + (j2 & 7)} offset:{KB1 + (j2 >> 3) * 8192}")      # a conflict-free address pattern (K's)
+                else:
+                    A(f"ds_read_b64_tr_b16 a[{slot}:{slot + 1}], v{V_VV + db2} offset:{VB + kk2 * 4096}")
+                    A(f"ds_read_b64_tr_b16 a[{slot + 2}:{slot + 3}], v{V_VV + db2} offset:{VB + kk2 * 4096 + 2048}")
         # ---- exponentials of P(t)
         for e in range(exps_before(g), exps_before(g + 1)):
             kk, qb, j = e >> 4, (e >> 3) & 1, e & 7
@@ -237,8 +240,7 @@ def main():
            "// ring buffers are compile-time), in two kinds (online running max / static row bound); register map and schedule:\n"
            "// the generator's docstring and the header of hv_attention_w4.hip.\n")
     text = hdr + "\n".join(emit_fn(f"w4_iter_{j}", j) for j in range(4))
-    if not STAMPS:
-        text += "\n" + "\n".join(emit_fn(f"w4_iter_{j}_static", j, True) for j in range(4))
+    text += "\n" + "\n".join(emit_fn(f"w4_iter_{j}_static", j, True) for j in range(4))
     return text
 
 
