@@ -1,21 +1,26 @@
 // Flash attention forward, bf16, head_dim 128 - the 4-wave x 64-row structure (one wave per SIMD, 512 registers per lane, the
 // accumulator half of the register file owned by inline asm through LITERAL register names).  Same arithmetic contract and the
-// same AttnArgs as the 8-wave kernel of hv_attention.hip (swapped QK^T, deferred running max in the C operand of the S chains,
-// P rounded to bf16 for P.V, unrounded row sums); what changes is who holds what:
+// same AttnArgs as the 8-wave kernels of rounds 1-2 (tools/attn_variants/): swapped QK^T, the maximum - a static row bound where it is
+// provably safe, else the deferred running max - in the C operand of the S chains, P rounded to bf16 for P.V, unrounded row sums;
+// what changed is who holds what:
 //
 //   workgroup = 4 waves = 256 query rows; a wave = 64 rows = two 32-row query blocks (qb).  Per 64-key tile and wave:
 //     S'^T[qb][kb] = K[kb] . Q'[qb]^T   2 x 2 chains of 8 v_mfma_f32_32x32x16_bf16           = 32 MFMAs
 //     O^T[qb][db] += V^T[db] . P^T[qb]  2 x 4 accumulator tiles x 4 k-steps of 16 keys       = 32 MFMAs
 //   and every K / V fragment read from LDS feeds BOTH query blocks: 16 ds_read_b128 + 32 ds_read_b64_tr_b16 per 64 MFMAs, half
-//   of what two 32-row waves of the 8-wave kernel read for the same work (the loop is clock/power-bound, the
-//   lever left is energy per MFMA).
+//   of what two 32-row waves of the 8-wave kernel read for the same work.  The price: a wave that is alone on its SIMD issues VALU /
+//   LDS instructions at about half the rate two co-resident waves get, so the loop is INSTRUCTION-ISSUE bound and every instruction
+//   taken out of it paid: 64 v_exp_f32, 64 v_add_f32, 32 v_cvt_pk_bf16_f32, 48 LDS reads, 8 DMA pieces and
+//   nothing else per 64 MFMAs in the static-bound mode.
 //
 // Register map (per lane; `a` registers are never named to the compiler except as clobbers, so it cannot shuttle them):
 //   a[0:127]    O^T[qb][db], tile (qb*4 + db) at a[16*(qb*4+db) : +15]            written only by the P.V MFMAs
 //   a[128:191]  Q'[qb][ks] = bf16(Q * scale * log2 e), fragment (qb*8 + ks) at a[128 + 4*(qb*8+ks) : +3]
 //   a[192:223]  K fragment ring, 8 slots of 4 (ds_read_b128 straight into the accumulator file)
 //   a[224:255]  V^T fragment ring, 8 slots of 4 (two ds_read_b64_tr_b16 each)
-//   v: S'(t) and S'(t+1) 2 x 64, -m (C operand of the S chains) 32, packed P 32, addresses / statistics ~ 30   (compiler-allocated)
+//   v: S'(t) and S'(t+1) 2 x 64, -m (C operand of the S chains) 32, packed P 32, sums / static addresses / DMA offsets / exponential
+//      ring ~ 44: pinned by "{v[..]}" constraints in the generated steady-state statements (tools/gen_attn_w4_asm.py has the map),
+//      compiler-allocated in the tail iterations
 // LDS: K and V tile rings, FOUR deep each (128 KiB; one workgroup per CU): the DMA of a tile never targets a buffer that is being
 // read in the same iteration, so its eight 1-KiB pieces per wave are spread over the S phase (one every fourth MFMA gap) instead
 // of sitting in a burst behind the barrier; K(t+3) and V(t+2) are issued during iteration t and retired by the COUNTED
@@ -25,10 +30,13 @@
 // three-deep ring rotated at run time cost 17 VALU instructions per tile: one XOR per K fragment read + the base updates).
 // Iteration t (64 MFMA gaps, one scheduling fence per gap; consumes S'(t), produces S'(t+1)):
 //   gaps  0-31  S'(t+1) chains, K fragment f = gap/2 for both query blocks | 40 of the 64 exp2 of P(t) (5 per 4 gaps), packs, row sums
-//   gaps 32-63  O += V(t).P(t), V fragment per two gaps                    | the other 24 exp2 (gaps 32-55), row max of S'(t+1)
+//   gaps 32-63  O += V(t).P(t), V fragment per two gaps                    | the other 24 exp2 (gaps 32-54), row max of S'(t+1) (online mode only)
 //   fragment f is read from LDS four fragments (eight gaps, > 256 cycles) ahead of its first MFMA, which waits with a counted
-//   lgkmcnt; barrier at gap 56 (vmcnt only: with three-deep rings no buffer read in this iteration is a DMA target before the next
-//   barrier), then the first four K fragments of the next tile.
+//   lgkmcnt (one wait per pair of fragments); barrier at gap 56 (vmcnt only: no buffer read in this iteration is a DMA target before
+//   the next barrier), then the first four K fragments of the next tile.
+// Maximum: AttnArgs::kmax2 given (a workspace and a long key range: hv_attention.hip) -> per wave, after tile 0, the STATIC row bound
+// |q'| |k|_max if it is within 90 of the row max of tile 0 for every row (see the decision in the prologue), else the online maximum
+// with the rare rescale through v_accvgpr_read / multiply / write.
 #include "hv_attention.hpp"
 #include "hv_agpr_clobbers.inc"
 
@@ -52,8 +60,8 @@ constexpr int WGRP = HV_W4_WGRP;   // one counted lgkmcnt wait per WGRP fragment
 // LDS instructions issued between fragment f's read and its first use = the reads of fragments f+1 .. f+PF-1 (K: 1 instruction,
 // V: 2; fragments 16..31 of a tile are V, 32.. are the next tile's K)
 __host__ __device__ constexpr int frag_insts(int f) { return (f >= 16 && f < 32) ? 2 : 1; }
-// one wait per PAIR of fragments (a wave alone on its SIMD pays ~4 issue cycles per s_waitcnt even when it is satisfied): the first
-// MFMA of an even fragment f waits until f AND f+1 have landed = all but the reads of f+2 .. f+PF-1
+// one wait per WGRP fragments: the first MFMA of fragment f (f % WGRP == 0) waits until f .. f+WGRP-1 have landed = all but the reads
+// of f+WGRP .. f+PF-1
 __host__ __device__ constexpr int wait_for(int f) { int n = 0; for (int i = WGRP; i < PF; ++i) n += frag_insts(f + i); return n; }
 
 // ---------------------------------------------------------------------------------------------------- asm building blocks
