@@ -27,6 +27,9 @@ A_O, A_Q, A_KF, A_VF = 0, 128, 192, 224
 RING = 8
 PF = int(os.environ.get("HV_W4_PF", "4"))       # fragments of LDS read-ahead (must match hv_attention_w4.hip)
 WGRP = int(os.environ.get("HV_W4_WGRP", "2"))   # one counted lgkmcnt wait per WGRP fragments (must match hv_attention_w4.hip)
+ORDER = os.environ.get("HV_W4_ORDER", "rdpaem")    # order of a gap's fillers behind its MFMA: fragment reads, DMA piece, packs, adds, exps, row max (memory first: +2.9 % over VALU first, profiles/r03/attn_filler_order.txt)
+EXPD = os.environ.get("HV_W4_EXPD", "")
+DOT = os.environ.get("HV_W4_DOT", "0") == "1"
 LAG = int(os.environ.get("HV_W4_LAG", "1"))       # gaps between a v_exp_f32 and the pack / row-sum add that read it
 EXR = 12                                          # ring of the last exponentials (>= 2 per gap x (LAG + 1) + the pair partner)
 V_NEGM, V_PW, V_EX, V_L, V_MX, V_VV, V_KOFF, V_VOFF, V_VKS = 128, 160, 222, 200, 202, 206, 212, 216, 236
@@ -46,6 +49,12 @@ def l_reg(qb, odd):
 def exps_before(g):
     """exponentials issued before gap g: 5 per 4 gaps through the S phase (gaps 0..31: 40), then one per gap, the last at gap 54 (two in
     gap 32), so that with the consumers up to LAG = 2 gaps behind, the pack of the last pair (gap <= 56) precedes its MFMA (gap 57)."""
+    if EXPD == "u":     # uniform over gaps 0..53
+        return min(64, (g * 64 + 53) // 54)
+    if EXPD == "f":     # 3 per 2 gaps through the S phase, 2 per 3 gaps after it
+        return g + g // 2 if g <= 32 else min(64, 48 + ((g - 32) * 2 + 2) // 3)
+    if EXPD == "b":     # one per gap through the S phase, 4 per 3 gaps after it
+        return g if g <= 32 else min(64, 32 + ((g - 32) * 4 + 2) // 3)
     if g <= 32:
         return g + (g + 3) // 4
     return min(64, 41 + (g - 32))
@@ -95,6 +104,7 @@ def gen_iter(j, static=False):
         if dma and ((g >> 2) & 3) == 0:      # M0 once per tensor: piece i adds i * 1024 through its immediate offset
             A(f"s_add_u32 m0, %[ldsw], {KD if g < 16 else VD}")
         # ---- MFMA
+        at_mfma = None
         if g < 32:
             f, qb = g >> 1, g & 1
             kb, ks = f >> 3, f & 7
@@ -102,6 +112,7 @@ def gen_iter(j, static=False):
             if qb == 0 and f % WGRP == 0:
                 A(f"s_waitcnt lgkmcnt({wait_for(f)})")
             c = f"v[{V_NEGM + 16 * qb}:{V_NEGM + 16 * qb + 15}]" if ks == 0 else s_tile(SN, qb, kb)
+            at_mfma = len(L)
             A(f"v_mfma_f32_32x32x16_bf16 {s_tile(SN, qb, kb)}, a[{kf}:{kf + 3}], a[{qf}:{qf + 3}], {c}")
         else:
             j = g - 32
@@ -110,6 +121,7 @@ def gen_iter(j, static=False):
             if qb == 0 and f % WGRP == 0:
                 A(f"s_waitcnt lgkmcnt({wait_for(f)})")
             pw = V_PW + 4 * (4 * qb + kk)
+            at_mfma = len(L)
             A(f"v_mfma_f32_32x32x16_bf16 a[{ot}:{ot + 15}], a[{vf}:{vf + 3}], v[{pw}:{pw + 3}], a[{ot}:{ot + 15}]")
         # ---- barrier: this wave's pieces of K(t+2) / V(t+1) by the counted vmcnt (the 8 youngest = this iteration's), everyone's by the barrier
         if g == 2 * (32 - PF):
@@ -130,59 +142,74 @@ def gen_iter(j, static=False):
                 A("s_add_u32 %[acc_bar], %[acc_bar], s98")
                 A("s_sub_u32 s98, s92, s90")
                 A("s_add_u32 %[acc_pre], %[acc_pre], s98")
-        # ---- packs and row-sum adds of the PREVIOUS gap's exponentials (the MFMA above separates them from their v_exp_f32)
+        # ---- the gap's fillers, collected by kind and emitted in ORDER (p packs, a adds, r fragment reads, e exponentials, m row max)
+        packs, adds, reads, exps, maxs = [], [], [], [], []
+        # packs and row-sum adds of the exponentials issued LAG gaps ago (the MFMAs in between separate them from their v_exp_f32)
         if g >= LAG:
             for e in range(exps_before(g - LAG), exps_before(g - LAG + 1)):
                 kk, qb, j = e >> 4, (e >> 3) & 1, e & 7
                 if j & 1:
-                    A(f"v_cvt_pk_bf16_f32 v{V_PW + 4 * (4 * qb + kk) + (j >> 1)}, {ex_reg(e - 1)}, {ex_reg(e)}")
+                    packs.append(f"v_cvt_pk_bf16_f32 v{V_PW + 4 * (4 * qb + kk) + (j >> 1)}, {ex_reg(e - 1)}, {ex_reg(e)}")
             for e in range(exps_before(g - LAG), exps_before(g - LAG + 1)):
-                qb = (e >> 3) & 1
+                kk, qb, j = e >> 4, (e >> 3) & 1, e & 7
+                if DOT:     # row sums from the PACKED words: one v_dot2c_f32_bf16 against (1.0, 1.0) per two exponentials (l then sums exactly the P the PV MFMA uses)
+                    if j & 1:
+                        adds.append(f"v_dot2c_f32_bf16 v{l_reg(qb, (j >> 1) & 1)}, 0x3f803f80, v{V_PW + 4 * (4 * qb + kk) + (j >> 1)}")
+                    continue
                 if PKADD:
                     if e & 1:
                         a0 = l_reg(qb, 0)
                         e0 = V_EX + ((e - 1) % EXR)
-                        A(f"v_pk_add_f32 v[{a0}:{a0 + 1}], v[{a0}:{a0 + 1}], v[{e0}:{e0 + 1}]")
+                        adds.append(f"v_pk_add_f32 v[{a0}:{a0 + 1}], v[{a0}:{a0 + 1}], v[{e0}:{e0 + 1}]")
                     continue
                 acc = l_reg(qb, e & 1)
-                A(f"v_add_f32 v{acc}, v{acc}, {ex_reg(e)}")
-        # ---- fragment reads, PF fragments ahead
+                adds.append(f"v_add_f32 v{acc}, v{acc}, {ex_reg(e)}")
+        # fragment reads, PF fragments ahead
         if g % 2 == 0:
             f2 = g // 2 + PF
             if f2 < 16 or f2 >= 32:
                 fk = f2 if f2 < 16 else f2 - 32
                 slot = A_KF + 4 * (f2 % RING)
                 ks, kb = fk & 7, fk >> 3
-                A(f"ds_read_b128 a[{slot}:{slot + 3}], v{V_VKS + ks} offset:{(KB1 if f2 < 16 else KB2) + kb * 8192}")
+                reads.append(f"ds_read_b128 a[{slot}:{slot + 3}], v{V_VKS + ks} offset:{(KB1 if f2 < 16 else KB2) + kb * 8192}")
             else:
                 j2 = f2 - 16
                 kk2, db2 = j2 >> 2, j2 & 3
                 slot = A_VF + 4 * (f2 % RING)
                 if "H" in ABL:      # timing only: what a V pre-transposed in HBM would issue - ONE 16-byte read per fragment (same bytes)
-                    A(f"ds_read_b128 a[{slot}:{slot + 3}], v{V_VKS + (j2 & 7)} offset:{KB1 + (j2 >> 3) * 8192}")      # a conflict-free address pattern (K's)
+                    reads.append(f"ds_read_b128 a[{slot}:{slot + 3}], v{V_VKS + (j2 & 7)} offset:{KB1 + (j2 >> 3) * 8192}")      # a conflict-free address pattern (K's)
                 else:
-                    A(f"ds_read_b64_tr_b16 a[{slot}:{slot + 1}], v{V_VV + db2} offset:{VB + kk2 * 4096}")
-                    A(f"ds_read_b64_tr_b16 a[{slot + 2}:{slot + 3}], v{V_VV + db2} offset:{VB + kk2 * 4096 + 2048}")
-        # ---- exponentials of P(t)
+                    reads.append(f"ds_read_b64_tr_b16 a[{slot}:{slot + 1}], v{V_VV + db2} offset:{VB + kk2 * 4096}")
+                    reads.append(f"ds_read_b64_tr_b16 a[{slot + 2}:{slot + 3}], v{V_VV + db2} offset:{VB + kk2 * 4096 + 2048}")
+        # exponentials of P(t)
         for e in range(exps_before(g), exps_before(g + 1)):
             kk, qb, j = e >> 4, (e >> 3) & 1, e & 7
-            A(f"v_exp_f32 {ex_reg(e)}, {s_reg(SC, qb, kk >> 1, 8 * (kk & 1) + j)}")
-        # ---- row max of S'(t+1): two values per gap, chain-complete order
+            exps.append(f"v_exp_f32 {ex_reg(e)}, {s_reg(SC, qb, kk >> 1, 8 * (kk & 1) + j)}")
+        # row max of S'(t+1): two values per gap, chain-complete order
         if g >= 32 and not static:
             mi = g - 32
             c = mi >> 3
             qb, kb, r = c & 1, c >> 1, 2 * (mi & 7)
             if kb == 0 and r == 0:
-                A(f"v_max_f32 v{V_MX + qb}, {s_reg(SN, qb, kb, r)}, {s_reg(SN, qb, kb, r + 1)}")
+                maxs.append(f"v_max_f32 v{V_MX + qb}, {s_reg(SN, qb, kb, r)}, {s_reg(SN, qb, kb, r + 1)}")
             else:
-                A(f"v_max3_f32 v{V_MX + qb}, v{V_MX + qb}, {s_reg(SN, qb, kb, r)}, {s_reg(SN, qb, kb, r + 1)}")
+                maxs.append(f"v_max3_f32 v{V_MX + qb}, v{V_MX + qb}, {s_reg(SN, qb, kb, r)}, {s_reg(SN, qb, kb, r + 1)}")
         # ---- DMA piece (K(t+3) at gaps 3..15, V(t+2) at gaps 19..31); M0 was written at the top of the gap
+        dmas = []
         if dma:
             i = (g >> 2) & 3
             if g < 16:
-                A(f"buffer_load_dwordx4 v{V_KOFF + i}, %[krs], 0 offen{f' offset:{i * 1024}' if i else ''} lds")
+                dmas.append(f"buffer_load_dwordx4 v{V_KOFF + i}, %[krs], 0 offen{f' offset:{i * 1024}' if i else ''} lds")
             else:
-                A(f"buffer_load_dwordx4 v{V_VOFF + i}, %[vrs], 0 offen{f' offset:{i * 1024}' if i else ''} lds")
+                dmas.append(f"buffer_load_dwordx4 v{V_VOFF + i}, %[vrs], 0 offen{f' offset:{i * 1024}' if i else ''} lds")
+        kinds = {"p": packs, "a": adds, "r": reads, "e": exps, "m": maxs, "d": dmas}
+        for kind in ORDER:      # an upper-case letter puts that kind in FRONT of the gap's MFMA (behind its wait)
+            if kind.isupper():
+                L[at_mfma:at_mfma] = kinds[kind.lower()]
+                at_mfma += len(kinds[kind.lower()])
+            else:
+                for ln in kinds[kind]:
+                    A(ln)
     if ABL:
         def drop(ln):
             op = ln.split()[0]
