@@ -29,6 +29,8 @@ PF = int(os.environ.get("HV_W4_PF", "4"))       # fragments of LDS read-ahead (m
 WGRP = int(os.environ.get("HV_W4_WGRP", "2"))   # one counted lgkmcnt wait per WGRP fragments (must match hv_attention_w4.hip)
 ORDER = os.environ.get("HV_W4_ORDER", "rdpaem")    # order of a gap's fillers behind its MFMA: fragment reads, DMA piece, packs, adds, exps, row max (memory first: +2.9 % over VALU first, profiles/r03/attn_filler_order.txt)
 EXPD = os.environ.get("HV_W4_EXPD", "")
+DMAPH = int(os.environ.get("HV_W4_DMAPH", "3"))     # the DMA pieces go to gaps = DMAPH (mod 4) of the S phase
+VSPLIT = os.environ.get("HV_W4_VSPLIT", "0") == "1"   # second half of a V fragment read one gap later
 DOT = os.environ.get("HV_W4_DOT", "0") == "1"
 LAG = int(os.environ.get("HV_W4_LAG", "1"))       # gaps between a v_exp_f32 and the pack / row-sum add that read it
 EXR = 12                                          # ring of the last exponentials (>= 2 per gap x (LAG + 1) + the pair partner)
@@ -100,7 +102,7 @@ def gen_iter(j, static=False):
             A("s_waitcnt lgkmcnt(0)")
             A("s_sub_u32 s98, s94, s90")
             A(f"s_add_u32 %[acc_p{g // 16}], %[acc_p{g // 16}], s98")
-        dma = g < 32 and (g & 3) == 3
+        dma = g < 32 and (g & 3) == DMAPH
         if dma and ((g >> 2) & 3) == 0:      # M0 once per tensor: piece i adds i * 1024 through its immediate offset
             A(f"s_add_u32 m0, %[ldsw], {KD if g < 16 else VD}")
         # ---- MFMA
@@ -180,7 +182,15 @@ def gen_iter(j, static=False):
                     reads.append(f"ds_read_b128 a[{slot}:{slot + 3}], v{V_VKS + (j2 & 7)} offset:{KB1 + (j2 >> 3) * 8192}")      # a conflict-free address pattern (K's)
                 else:
                     reads.append(f"ds_read_b64_tr_b16 a[{slot}:{slot + 1}], v{V_VV + db2} offset:{VB + kk2 * 4096}")
-                    reads.append(f"ds_read_b64_tr_b16 a[{slot + 2}:{slot + 3}], v{V_VV + db2} offset:{VB + kk2 * 4096 + 2048}")
+                    if not VSPLIT:
+                        reads.append(f"ds_read_b64_tr_b16 a[{slot + 2}:{slot + 3}], v{V_VV + db2} offset:{VB + kk2 * 4096 + 2048}")
+        elif VSPLIT and "H" not in ABL:
+            f2 = g // 2 + PF
+            if 16 <= f2 < 32:
+                j2 = f2 - 16
+                kk2, db2 = j2 >> 2, j2 & 3
+                slot = A_VF + 4 * (f2 % RING)
+                reads.append(f"ds_read_b64_tr_b16 a[{slot + 2}:{slot + 3}], v{V_VV + db2} offset:{VB + kk2 * 4096 + 2048}")
         # exponentials of P(t)
         for e in range(exps_before(g), exps_before(g + 1)):
             kk, qb, j = e >> 4, (e >> 3) & 1, e & 7
@@ -213,6 +223,8 @@ def gen_iter(j, static=False):
     if ABL:
         def drop(ln):
             op = ln.split()[0]
+            if "P" in ABL and op == "v_cvt_pk_bf16_f32":
+                return False
             if "v" in ABL and op in ("v_exp_f32", "v_add_f32", "v_cvt_pk_bf16_f32", "v_max3_f32", "v_max_f32"):
                 return True
             if "m" in ABL and op in ("v_max3_f32", "v_max_f32"):
@@ -225,6 +237,13 @@ def gen_iter(j, static=False):
                 return True
             return False
         L = [ln for ln in L if not drop(ln)]
+        if "P" in ABL:      # timing only: truncating pack by v_perm_b32 instead of v_cvt_pk_bf16_f32
+            def perm(ln):
+                if not ln.startswith("v_cvt_pk_bf16_f32"):
+                    return ln
+                d, a, b = [x.strip() for x in ln.split(None, 1)[1].split(",")]
+                return f"v_perm_b32 {d}, {b}, {a}, s99"
+            L = ["s_mov_b32 s99, 0x07060302"] + [perm(ln) for ln in L]
         if "m" in ABL:
             L += [f"v_mov_b32 v{V_MX}, 0", f"v_mov_b32 v{V_MX + 1}, 0"]
     return L
@@ -244,6 +263,8 @@ def emit_fn(name, j, static=False):
     dbg_out = ', [acc_vm] "+s"(acc_vm), [acc_bar] "+s"(acc_bar), [acc_pre] "+s"(acc_pre), [acc_p1] "+s"(acc_p1), [acc_p2] "+s"(acc_p2), [acc_p3] "+s"(acc_p3)' if STAMPS else ""
     if STAMPS:
         clob += [f'"s{i}"' for i in range(90, 99)]
+    if "P" in ABL:
+        clob += ['"s99"']
     mx_arg = "" if static else "float (&mx)[2], "
     mx_out = "" if static else f', "={{v{V_MX}}}"(mx[0]), "={{v{V_MX + 1}}}"(mx[1])'
     kind = "static row bound in -m: no row max of S'(t+1), never a rescale" if static else "online (deferred) running max: row max of S'(t+1) in mx"
