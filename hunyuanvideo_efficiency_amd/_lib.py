@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhv_kernels.so")
@@ -32,6 +33,7 @@ SIGNATURES = {
     "hv_timestep_embedding_bf16": [_p, _p, _i, _i, _f, _p],
     "hv_attn_fwd_bf16": [_p, _p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _f, _p, _l, _p],
     "hv_attn_workspace_bytes": [_i, _i, _i],
+    "hv_attn_w4_loop_signature": [],
     "hv_attn_partial_bf16": [_p, _p, _p, _l, _l, _l, _i, _i, _i, _i, _f, _p, _p, _i, _i, _i, _p],
     "hv_attn_merge_bf16": [_p, _p, _p, _l, _i, _i, _i, _p],
     "hv_attn_suggest_splits": [_i, _i, _i],
@@ -92,6 +94,15 @@ def load():
     v = lib.hv_abi_version()
     if v != ABI_VERSION:
         raise HVKernelError(f"libhv_kernels ABI {v} != expected {ABI_VERSION}: rebuild the extension")
+    # the attention kernel's steady-state iteration is generated code (csrc/hv_attention_w4_loop.inc): a library compiled from another
+    # iteration - a stale file or a timing experiment's, which computes garbage by design - must not pass for the product
+    inc = os.path.join(_HERE, "csrc", "hv_attention_w4_loop.inc")
+    if os.path.exists(inc) and os.environ.get("HV_ALLOW_EXPERIMENT_LIB") != "1":
+        with open(inc) as f:
+            m = re.search(r"#define HV_W4_LOOP_SIGNATURE 0x([0-9a-f]{8})u", f.read(600))
+        if m is None or (lib.hv_attn_w4_loop_signature() & 0xFFFFFFFF) != int(m.group(1), 16):
+            raise HVKernelError(f"{LIB_PATH} was not compiled from {inc}: rebuild the extension (make -C hunyuanvideo_efficiency_amd/csrc); "
+                                "HV_ALLOW_EXPERIMENT_LIB=1 admits an experiment build (tools/attn_variants)")
     _lib = lib
     return lib
 

@@ -130,12 +130,17 @@ __device__ __forceinline__ float acc_read() {
 }
 
 // the steady-state iteration as ONE asm statement with literal registers (tools/gen_attn_w4_asm.py)
-#ifdef HV_W4_STAMPS      // diagnostic build (tools/attn_variants): the generated iteration with s_memtime stamps around the barrier's waits
+#if defined(HV_W4_LOOP_INC)  // experiment builds (tools/attn_variants/build_w4.sh): an iteration generated outside the tree, never the product's
+#include HV_W4_LOOP_INC
+#elif defined(HV_W4_STAMPS)  // diagnostic build: the generated iteration with s_memtime stamps around the barrier's waits
 #include "hv_attention_w4_loop_stamps.inc"
+#else
+#include "hv_attention_w4_loop.inc"
+#endif
+#ifdef HV_W4_STAMPS
 __device__ unsigned g_w4_dbg[8];
 #define HV_W4_DBG_ARGS , dbg_vm, dbg_bar, dbg_pre, dbg_p1, dbg_p2, dbg_p3
 #else
-#include "hv_attention_w4_loop.inc"
 #define HV_W4_DBG_ARGS
 #endif
 
@@ -655,6 +660,8 @@ HvPerDeviceOnce g_w4_lds_once;
 
 }  // namespace
 
+// crc32 of the generated iteration this library was compiled from (tests/test_capi_cpu.py compares it with the in-tree .inc)
+extern "C" int hv_attn_w4_loop_signature(void) { return (int)HV_W4_LOOP_SIGNATURE; }
 #ifdef HV_W4_STAMPS
 extern "C" int hv_attn_w4_debug_read(unsigned* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_dbg), sizeof(unsigned) * 8) == hipSuccess ? 0 : -1; }
 #endif

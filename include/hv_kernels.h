@@ -96,6 +96,9 @@ int hv_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64
 
 /* bytes of scratch hv_attn_fwd_bf16 can use: the 256-byte bound area + the partials of a 2-way KV split (returned as int64). */
 int64_t hv_attn_workspace_bytes(int n_q, int n_kv, int n_heads);
+/* crc32 of the generated steady-state iteration (csrc/hv_attention_w4_loop.inc, `#define HV_W4_LOOP_SIGNATURE`) the library's attention
+ * kernel was compiled from: lets a host check that the library in front of it is the product build and not a timing experiment. */
+int hv_attn_w4_loop_signature(void);        /* the 32 bits of the crc, as int */
 
 /* Ring attention (hybrid Ulysses x Ring, xfuser `ring_degree > 1`: hyvideo/inference.py:171-175, call site
  * modules/attenion.py:169-180): the queries of one rank against ONE K/V chunk.  Leaves the unnormalised partial in slot(s)

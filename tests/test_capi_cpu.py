@@ -87,6 +87,12 @@ def test_generated_attention_iteration_is_up_to_date_and_consistent():
     spec.loader.exec_module(g)
     assert not g.STAMPS and not g.ABL
     assert open(g.OUT).read() == g.main(), "run python tools/gen_attn_w4_asm.py"
+    # ... and the built library was compiled from exactly this file (not from a stale one, not from a timing experiment's)
+    import ctypes
+    from hunyuanvideo_efficiency_amd import _lib
+    sig = int(re.search(r"#define HV_W4_LOOP_SIGNATURE 0x([0-9a-f]{8})u", open(g.OUT).read()).group(1), 16)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    assert (lib.hv_attn_w4_loop_signature() & 0xFFFFFFFF) == sig, "libhv_kernels.so is not built from the in-tree iteration: make -C hunyuanvideo_efficiency_amd/csrc"
     body = g.gen_iter(0)
     gaps, cur = [], None
     for ln in body:

@@ -1,6 +1,7 @@
 #!/bin/bash
 # One gpurun call: (1) the attention parity tests with ab_libs/<variant>.so swapped in for the product library, (2) a same-box
 # A/B of the named libraries at the bench shape (tools/ab_attn.sh).   usage: check_and_ab.sh <variant> <baseline>
+export HV_ALLOW_EXPERIMENT_LIB=1     # experiment libraries are swapped in below
 set -o pipefail
 V=$1; B=$2
 cp hunyuanvideo_efficiency_amd/lib/libhv_kernels.so /tmp/libhv_kernels.product.so

@@ -287,9 +287,13 @@ def main():
            "// The steady-state iteration of attn_fwd_kernel_w4 as one inline-asm statement per position in the x4 unrolled loop (S-buffer role and\n"
            "// ring buffers are compile-time), in two kinds (online running max / static row bound); register map and schedule:\n"
            "// the generator's docstring and the header of hv_attention_w4.hip.\n")
-    text = hdr + "\n".join(emit_fn(f"w4_iter_{j}", j) for j in range(4))
-    text += "\n" + "\n".join(emit_fn(f"w4_iter_{j}_static", j, True) for j in range(4))
-    return text
+    body = "\n".join(emit_fn(f"w4_iter_{j}", j) for j in range(4))
+    body += "\n" + "\n".join(emit_fn(f"w4_iter_{j}_static", j, True) for j in range(4))
+    # the library reports this number (hv_attn_w4_loop_signature): tests compare it with the in-tree file, so a library built from an
+    # experiment's iteration (or from a stale one) cannot pass for the product
+    import zlib
+    sig = zlib.crc32(body.encode()) & 0xFFFFFFFF
+    return hdr + f"#define HV_W4_LOOP_SIGNATURE 0x{sig:08x}u\n" + body
 
 
 if __name__ == "__main__":
