@@ -19,6 +19,7 @@ Register map (arch VGPRs pinned by "{v[..]}" constraints, accumulator registers 
 Schedule per iteration t (64 MFMA gaps): see hv_attention_w4.hip header; the tables here are the single source of it.
 """
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.environ.get("HV_W4_INC_OUT") or os.path.join(ROOT, "hunyuanvideo_efficiency_amd", "csrc", "hv_attention_w4_loop.inc")
@@ -237,6 +238,16 @@ def gen_iter(j, static=False):
                 return True
             return False
         L = [ln for ln in L if not drop(ln)]
+        if "S" in ABL:      # timing only: every 32x32x16 MFMA as two 16x16x32 on the same operand registers (same flops, same operand data, garbage results)
+            def split(ln):
+                if not ln.startswith("v_mfma_f32_32x32x16_bf16"):
+                    return [ln]
+                d, a, b, c = [x.strip() for x in ln.split(None, 1)[1].split(", ")]
+                def quad(r, i):
+                    pre, lo = re.match(r"([av])\[(\d+):\d+\]", r).groups()
+                    return f"{pre}[{int(lo) + 4 * i}:{int(lo) + 4 * i + 3}]"
+                return [f"v_mfma_f32_16x16x32_bf16 {quad(d, i)}, {a}, {b}, {quad(c, i)}" for i in range(2)]
+            L = [x for ln in L for x in split(ln)]
         if "P" in ABL:      # timing only: truncating pack by v_perm_b32 instead of v_cvt_pk_bf16_f32
             def perm(ln):
                 if not ln.startswith("v_cvt_pk_bf16_f32"):
