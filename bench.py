@@ -385,7 +385,10 @@ def main():
             "roofline": {"kernel": "attn_fwd_kernel (hv_attn_fwd_bf16, main segment)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note,
-                         "launches": len(att_ms), "avg_launch_ms": avg_ms, "flop_per_launch": avg_flop},
+                         "launches": len(att_ms), "avg_launch_ms": avg_ms, "flop_per_launch": avg_flop,
+                         "peak_note": "peak = dense bf16 MFMA at full clock, as the contract says.  Cited, not live (profiles/r03/mfma_power_roof.txt, "
+                                      "attn_power_clock.txt): under the 1400 W cap a BARE v_mfma_f32_32x32x16_bf16 stream sustains 1780-1850 TFLOP/s on "
+                                      "random bf16 operands (2470 on zeros); this kernel's own instruction stream runs at 2256 TFLOP/s on all-zero inputs"},
         }
         if secondary:
             out["secondary"] = secondary
