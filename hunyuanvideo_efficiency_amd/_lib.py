@@ -58,6 +58,8 @@ SIGNATURES = {
     "hv_softmax_rows_f32_f16": [_p, _l, _p, _l, _i, _i, _i, _f, _i, _p],
     "hv_transpose_16b": [_p, _l, _p, _l, _i, _i, _p],
     "hv_conv3d_upsampled_subpixel_f16": [_p, _l, _p, _p, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p, _l, _p],
+    "hv_conv3d_cout4_f16": [_p, _l, _p, _i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p, _l, _p],
+    "hv_conv3d_cout4_planes_floats": [_l],
     "hv_conv3d_causal_strided_f16": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hv_temporal_resample_f16": [_p, _l, _p, _l, _i, _l, _i, _i, _i, _i, _p],
     "hv_vae_latent_tile_f16": [_p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _p, _p],
@@ -90,7 +92,7 @@ def load():
         except AttributeError as e:
             raise HVKernelError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name in ("hv_attn_workspace_bytes", "hv_gn_partial_rows", "hv_subpixel_gn_partial_rows") else C.c_int
+        fn.restype = C.c_int64 if name in ("hv_attn_workspace_bytes", "hv_gn_partial_rows", "hv_subpixel_gn_partial_rows", "hv_conv3d_cout4_planes_floats") else C.c_int
     v = lib.hv_abi_version()
     if v != ABI_VERSION:
         raise HVKernelError(f"libhv_kernels ABI {v} != expected {ABI_VERSION}: rebuild the extension")

@@ -227,6 +227,124 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
     }
 }
 
+// ---- conv_out (DecoderCausal3D.conv_out, 128 -> 3; vae.py:283-294) as 27 per-tap PLANES + a gather-sum.
+// A 3x3x3 conv with Cout <= 4 is HBM-bound work (10 kFLOP per 256-byte voxel), but as an implicit GEMM it stages every activation
+// nine times for a 256 x 8 output tile (conv128s_narrow_kernel: 2.1 ms per 65x256x256 tile, after a 0.39 ms GroupNorm pass that
+// writes what it reads).  Here the GroupNorm affine + SiLU in front of it and the channel contraction run in ONE streaming pass
+//     planes[tap][voxel][c] = sum_ch  w[c][ch][tap] * silu(x[voxel][ch] * scale[ch] + shift[ch])        (fp32, c < 3)
+// - every activation read once, normalised in registers exactly as gn_apply_kernel does (fp32 affine, SiLU, one rounding to fp16),
+// contracted by v_mfma_f32_16x16x32_f16 with the whole weight set (28 fragments) resident in registers - and a second pass sums the
+// 27 planes at the tap-shifted voxels (replicate padding in H/W, causal in T = clamped indices, the conv kernels' gather rule):
+//     out[v][c] = bias[c] + sum_tap planes[tap][shift_tap(v)][c]         in the fixed order tap = 0..26, fp32, one rounding to fp16.
+// Operand roles: A = weights (row i = 4 * tap' + c of a 16-row block: 4 taps x (3 channels + 1 zero row)), B = activations (column
+// j = voxel of a 16-voxel group), so a lane's four accumulator registers are the channels of ONE (tap, voxel): a 12-byte store into
+// a plane that is contiguous over voxels.  Traffic per voxel: 256 B read + 324 B written, then 324 B read + 16 B written.
+constexpr int CO4_NB = 7;                 // 16-row blocks of (tap, channel) rows: 4 taps each, 27 taps -> 7
+
+template <bool SILU>
+__global__ __launch_bounds__(256, 2) void conv_cout4_planes_kernel(const uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ affine,
+                                                                 const u32x4* __restrict__ w_frag, float* __restrict__ planes, int64_t M, int nks) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
+    u32x4 wf[CO4_NB][4];                  // [row block][k step]: rows = lane & 15, k = 8 * (lane >> 4) .. + 7 of the step
+#pragma unroll
+    for (int nb = 0; nb < CO4_NB; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wf[nb][ks] = ks < nks ? w_frag[(nb * 4 + ks) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    // the affine in LDS as [k step][lane >> 4][scale x 8 | shift x 8]: a lane reads its 16 floats of a k step with four 16-byte reads
+    // (64 registers otherwise: with them the kernel holds one wave per SIMD)
+    __shared__ __attribute__((aligned(16))) float aff_s[4 * 4 * 16];
+    if (affine) {
+        for (int i = threadIdx.x; i < 4 * 4 * 16; i += 256) {
+            const int ks = i >> 6, q = (i >> 4) & 3, j = i & 7, ch = ks * 32 + q * 8 + j;
+            aff_s[i] = ks < nks ? affine[2 * ch + ((i >> 3) & 1)] : 0.f;
+        }
+        __syncthreads();
+    }
+    const int64_t ngrp = (M + 15) >> 4;
+    auto load = [&](int64_t g, u32x4 (&raw)[4]) {
+        const uint16_t* xp = x + min(g * 16 + fr, M - 1) * ldx + fq * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            if (ks < nks) raw[ks] = *reinterpret_cast<const u32x4*>(xp + ks * 32);
+    };
+    u32x4 cur[4], nxt[4];
+    if (wave < ngrp) load(wave, cur);
+    for (int64_t g = wave; g < ngrp; g += nwave) {
+        if (g + nwave < ngrp) load(g + nwave, nxt);        // the next group's rows are in flight while this one is normalised and contracted
+        f32x4 acc[CO4_NB];
+#pragma unroll
+        for (int nb = 0; nb < CO4_NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks >= nks) break;
+            u32x4 b = cur[ks];
+            if (affine) {
+                float v[8], o[8], sc[8], sh[8];
+                const f32x4* ap = reinterpret_cast<const f32x4*>(aff_s + (ks * 4 + fq) * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc[j] = ap[0][j], sc[4 + j] = ap[1][j], sh[j] = ap[2][j], sh[4 + j] = ap[3][j];
+                unpack8h(b, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = v[j] * sc[j] + sh[j];
+                    o[j] = SILU ? silu_f(t) : t;
+                }
+                b = pack8h(o);
+            }
+#pragma unroll
+            for (int nb = 0; nb < CO4_NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[nb][ks]), __builtin_bit_cast(f16x8, b), acc[nb], 0, 0, 0);
+        }
+        const int64_t v = g * 16 + fr;
+        if (v < M) {
+#pragma unroll
+            for (int nb = 0; nb < CO4_NB; ++nb) {
+                const int tap = nb * 4 + fq;
+                if (tap < 27) {
+                    float* o = planes + ((int64_t)tap * M + v) * 3;
+                    o[0] = acc[nb][0], o[1] = acc[nb][1], o[2] = acc[nb][2];
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) cur[ks] = nxt[ks];
+    }
+}
+
+// out[v][0..7] = fp16(bias[c] + sum_tap planes[tap][src_tap(v)][c]) for c < 3, zeros behind: one thread per voxel, 27 independent
+// 12-byte loads (contiguous over the lanes of a wave wherever the shift does not clamp)
+__global__ __launch_bounds__(256) void conv_cout4_gather_kernel(const float* __restrict__ planes, const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
+                                                                 int64_t ldo, int T, int H, int W, int cout) {
+    const int64_t M = (int64_t)T * H * W;
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= M) return;
+    const int w = (int)(v % W), h = (int)((v / W) % H), t = (int)(v / ((int64_t)W * H));
+    float a[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[c] = c < cout ? h2f(bias[c]) : 0.f;
+    float p[27][3];
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+        const int ti = max(t + dt - 2, 0), hi = min(max(h + dh - 1, 0), H - 1), wi = min(max(w + dw - 1, 0), W - 1);
+        const float* src = planes + ((int64_t)tap * M + ((int64_t)ti * H + hi) * W + wi) * 3;
+        p[tap][0] = src[0], p[tap][1] = src[1], p[tap][2] = src[2];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[c] += p[tap][c];
+    u32x4 o = {0u, 0u, 0u, 0u};
+    o[0] = (uint32_t)f2h(a[0]) | ((uint32_t)f2h(a[1]) << 16);
+    o[1] = (uint32_t)f2h(a[2]);
+    if (ldo >= 8) *reinterpret_cast<u32x4*>(out + v * ldo) = o;
+    else {
+        for (int c = 0; c < cout; ++c) out[v * ldo + c] = f2h(a[c]);
+    }
+}
+
 // ---- row softmax: P[r][c] = softmax_c(scale * S[r][c]) for c < valid(r), 0 for valid(r) <= c < cols_pad; fp32 in, fp16 out.
 // valid(r) = cols, or with causal_block > 0 the frame-causal mask of prepare_causal_attention_mask (unet_causal_3d_blocks.py:38-46):
 // min(cols, (r / causal_block + 1) * causal_block) - a query of frame f sees the keys of frames <= f.  VEC = 4: float4 loads and
@@ -447,6 +565,29 @@ extern "C" int hv_groupnorm_apply_f16(const void* x, int64_t ldx, void* y, int64
         gn_apply_kernel<true><<<grid, dim3(256), 0, stream>>>((const uint16_t*)x, ldx, (uint16_t*)y, ldy, M, C, affine);
     else
         gn_apply_kernel<false><<<grid, dim3(256), 0, stream>>>((const uint16_t*)x, ldx, (uint16_t*)y, ldy, M, C, affine);
+    return hv_check_launch();
+}
+
+extern "C" int64_t hv_conv3d_cout4_planes_floats(int64_t M) { return M > 0 ? 27 * M * 3 : 0; }
+
+extern "C" int hv_conv3d_cout4_f16(const void* x, int64_t ldx, const float* affine, int silu, const void* w_frag, const void* bias, void* out,
+                                   int64_t ldo, int T, int H, int W, int Cin, int Cout, float* planes, int64_t planes_floats, hipStream_t stream) {
+    if (!x || !w_frag || !bias || !out || !planes || T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > 128 || (Cin & 31) || Cout <= 0 || Cout > 3 ||
+        ldx < Cin || (ldx & 7) || ldo < Cout || (ldo >= 8 && (ldo & 7)) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)w_frag & 15))
+        return HV_ERR_ARG;
+    const int64_t M = (int64_t)T * H * W;
+    if (planes_floats < hv_conv3d_cout4_planes_floats(M)) return HV_ERR_ARG;
+    const int64_t ngrp = (M + 15) >> 4;
+    const int64_t want = (ngrp + 3) / 4;
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);      // 4 waves per block, each walks 16-voxel groups grid-stride
+    if (silu)
+        conv_cout4_planes_kernel<true><<<dim3(blocks), dim3(256), 0, stream>>>((const uint16_t*)x, ldx, affine, (const u32x4*)w_frag, planes, M, Cin / 32);
+    else
+        conv_cout4_planes_kernel<false><<<dim3(blocks), dim3(256), 0, stream>>>((const uint16_t*)x, ldx, affine, (const u32x4*)w_frag, planes, M, Cin / 32);
+    if (int rc = hv_check_launch(); rc != HV_OK) return rc;
+    const int64_t gblk = (M + 255) / 256;
+    if (gblk > 0x7fffffff) return HV_ERR_ARG;
+    conv_cout4_gather_kernel<<<dim3((unsigned)gblk), dim3(256), 0, stream>>>(planes, (const uint16_t*)bias, (uint16_t*)out, ldo, T, H, W, Cout);
     return hv_check_launch();
 }
 

@@ -239,6 +239,12 @@ class AutoencoderKLCausal3D(nn.Module):
             if cip >= 256 and (cip & (cip - 1)) == 0 and cop > 128:
                 w_sub, table, ntap = V.subpixel_weights(sd[name + ".weight"].to(dev), tm, mode, cip, cop)
                 P[name + "#subpixel"] = (w_sub, table, ntap, bp, cip, cop)
+        # the decoder's tail (conv_norm_out + SiLU + conv_out) as one streaming pass + a gather-sum (vae_ops.conv_cout4)
+        name = "decoder.conv_out.conv"
+        if V.conv_out_mode() == "planes" and name in P:
+            w = sd[name + ".weight"]
+            if w.shape[0] <= 3 and w.shape[1] <= 128 and w.shape[1] % 32 == 0:
+                P[name + "#cout4"] = (V.cout4_weight_fragments(w.to(dev)), P[name][1], int(w.shape[1]), int(w.shape[0]))
         self._prep = P
         return P
 
@@ -366,6 +372,11 @@ class AutoencoderKLCausal3D(nn.Module):
                     h = self._conv(P, name, h, T2, H2, W2, up_t=tm, up_hw=sp, gn_stats=feeds_gn)
                 h, st = h if feeds_gn else (h, None)
                 T, H, W = T2, H2, W2
+        if pre + "conv_out.conv#cout4" in P and h.shape[1] == P[pre + "conv_out.conv#cout4"][2]:
+            wf, b, ci, co = P[pre + "conv_out.conv#cout4"]
+            gw, gb = P[pre + "conv_norm_out"]
+            aff = V.groupnorm_affine_from_stats(st, gw, gb, 32, 1e-6) if st is not None else V.groupnorm_affine(h, gw, gb, 32, 1e-6)
+            return V.conv_cout4(h, aff, True, wf, b, T, H, W, ci, co), T, H, W
         h = self._gn(P, pre + "conv_norm_out", h, stats=st)
         out = self._conv(P, pre + "conv_out.conv", h, T, H, W)
         return out, T, H, W

@@ -83,6 +83,44 @@ def conv3d_causal(x, w_taps, bias, T: int, H: int, W: int, cin: int, cout: int, 
     return (out, st) if gn_stats else out
 
 
+def conv_out_mode() -> str:
+    """HV_VAE_CONV_OUT = planes (default) | gemm: the decoder's conv_norm_out + SiLU + conv_out as hv_conv3d_cout4_f16 (one streaming
+    pass + a gather-sum) or as GroupNorm apply + the narrow implicit-GEMM conv (the form before; kept for A/B)."""
+    import os
+    m = os.environ.get("HV_VAE_CONV_OUT", "planes")
+    if m not in ("planes", "gemm"):
+        raise ValueError(f"HV_VAE_CONV_OUT={m!r}: expected planes or gemm")
+    return m
+
+
+def cout4_weight_fragments(w):
+    """Conv3d weight [Cout <= 3, Cin <= 128, 3, 3, 3] -> the MFMA fragment order hv_conv3d_cout4_f16 reads, fp16 [7, 4, 64, 8]:
+    element (nb, ks, lane, j) = w[c][ks*32 + 8*(lane >> 4) + j][tap] with 4*tap + c = 16*nb + (lane & 15); zero rows for c == 3,
+    tap >= 27 and channels >= Cin (include/hv_kernels.h)."""
+    co, ci = w.shape[:2]
+    assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and co <= 3 and ci <= 128 and ci % 32 == 0, tuple(w.shape)
+    wn = torch.zeros(28, 4, 128, dtype=F16, device=w.device)                # [tap][c][channel]
+    wn[:27, :co, :ci] = w.detach().to(F16).reshape(co, ci, 27).permute(2, 0, 1)
+    wn = wn.reshape(7, 16, 4, 4, 8)                                         # [nb][row i][ks][lane >> 4][j]
+    return wn.permute(0, 2, 3, 1, 4).reshape(7, 4, 64, 8).contiguous()      # lane = (lane >> 4) * 16 + i
+
+
+def conv_cout4(x, affine, silu: bool, w_frag, bias, T: int, H: int, W: int, cin: int, cout: int, out=None):
+    """GroupNorm affine (+ SiLU) + 3x3x3 causal conv to cout <= 3 channels (hv_conv3d_cout4_f16); returns fp16 [T*H*W, 8], columns
+    cout.. zero.  affine: fp32 [cin, 2] or None (x is convolved as it is)."""
+    _chk(x, F16, "x"), _chk(w_frag, F16, "w_frag"), _chk(bias, F16, "bias")
+    if affine is not None:
+        _chk(affine, torch.float32, "affine")
+    m = T * H * W
+    assert x.shape[0] == m and x.shape[1] >= cin and tuple(w_frag.shape) == (7, 4, 64, 8), (x.shape, m, cin, w_frag.shape)
+    if out is None:
+        out = torch.empty(m, 8, dtype=F16, device=x.device)
+    n = _lib.host("conv3d_cout4_planes_floats", m)
+    planes = torch.empty(n, dtype=torch.float32, device=x.device)
+    _lib.call("conv3d_cout4_f16", x, x.stride(0), affine, int(silu), w_frag, bias, out, out.stride(0), T, H, W, cin, cout, planes, n)
+    return out
+
+
 def subpixel_mode() -> str:
     """HV_VAE_SUBPIXEL = fast (default) | exact | off: how UpsampleCausal3D's conv runs, see subpixel_weights()."""
     import os

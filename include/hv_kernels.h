@@ -217,6 +217,21 @@ int hv_conv3d_upsampled_subpixel_f16(const void* x, int64_t ldx, const void* w_s
                                      const void* bias, void* out, int64_t ldo, int sT, int sH, int sW, int Cin, int Cout,
                                      int up_t, float* gn_partial, int64_t gn_partial_floats, hipStream_t stream);
 
+/* DecoderCausal3D tail (vae.py:283-294: conv_norm_out -> SiLU -> conv_out): GroupNorm apply + SiLU + the 3x3x3 causal conv to
+ * Cout <= 3 channels in two streaming passes instead of an HBM pass and an implicit GEMM that stages every activation nine times:
+ *   planes[tap][voxel][c] = sum_ch w[c][ch][tap] * act(x[voxel][ch] * affine[ch][0] + affine[ch][1])      fp32, every voxel read once
+ *   out[voxel][c] = fp16(bias[c] + sum_{tap = 0..26} planes[tap][clamped tap-shifted voxel][c])           padding rule of hv_conv3d_causal_f16
+ * x: channels-last fp16 [T*H*W][ldx >= Cin]; affine (nullable: x is used as it is): fp32 [Cin][2] (scale, shift) as
+ * hv_groupnorm_finalize_f16 / hv_groupnorm_affine_f16 leave it, applied in fp32 and rounded to fp16 once - the arithmetic of
+ * hv_groupnorm_apply_f16; silu: 0 | 1.  w_frag: the weights in MFMA fragment order, fp16 [7][4][64][8]: row block nb, k step ks, lane l,
+ * element j = w[c][ks*32 + 8*(l>>4) + j][tap] with 4*tap + c = 16*nb + (l & 15), zero for c == 3, tap >= 27 and channels >= Cin
+ * (vae_ops.cout4_weight_fragments builds it).  out: [T*H*W][ldo]: ldo >= 8: columns Cout..7 are written as zeros (one 16-byte store).
+ * planes: workspace of hv_conv3d_cout4_planes_floats(T*H*W) floats.  Cin % 32 == 0, Cin <= 128, Cout <= 3.  The sum over the taps is
+ * taken in a fixed order: results are run-to-run identical (not bit-identical to hv_conv3d_causal_f16: another summation order). */
+int hv_conv3d_cout4_f16(const void* x, int64_t ldx, const float* affine, int silu, const void* w_frag, const void* bias, void* out,
+                        int64_t ldo, int T, int H, int W, int Cin, int Cout, float* planes, int64_t planes_floats, hipStream_t stream);
+int64_t hv_conv3d_cout4_planes_floats(int64_t M);
+
 /* DownsampleCausal3D (VAE encoder, unet_causal_3d_blocks.py:185-247): the same padding as hv_conv3d_causal_f16, then the 3x3x3
  * conv with stride 1|2 per axis (the fork's t_ops `downsample_stride` override, :737-742, changes these strides).
  * x: source [sT,sH,sW,Cin]; out: [T*H*W, Cout] with T = (sT-1)/stride_t + 1, H = (sH-1)/stride_h + 1, W likewise. */

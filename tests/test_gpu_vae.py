@@ -165,6 +165,45 @@ def test_groupnorm_silu(V, M_thw, C):
         torch.testing.assert_close(uncl(got, T, H, W), ref, rtol=2e-3, atol=2e-3)
 
 
+# The decoder's tail - GroupNorm(32) + SiLU + conv_out (Cout = 3) - as hv_conv3d_cout4_f16 (one streaming pass that normalises and
+# contracts the channels per tap, then a gather-sum over the 27 tap-shifted planes) against the oracle chain
+# group_norm_silu -> round to fp16 -> causal_conv3d, and against the form it replaces (hv_groupnorm_apply_f16 + the implicit-GEMM conv):
+# both see the same fp16 activations, only the fp32 summation order differs, so they agree to an fp16 ulp of the result.  Shapes: ragged
+# last 16-voxel group, T = 1 (every dt tap clamps to frame 0), W = 1 / H = 1 (every dw / dh tap clamps), Cin 32 / 64 / 128, Cout 1..3,
+# and no affine at all (a plain conv).
+@pytest.mark.parametrize("T,H,W,Cin,Cout,with_gn", [(3, 5, 7, 128, 3, True), (1, 4, 16, 128, 3, True), (2, 1, 9, 64, 3, True),
+                                                    (4, 6, 1, 32, 2, True), (2, 9, 33, 128, 3, False), (5, 16, 16, 64, 1, True)])
+def test_conv_out_planes_vs_oracle_and_gemm_form(V, T, H, W, Cin, Cout, with_gn):
+    x = E.r(U((1, Cin, T, H, W), "co.x", 2.0) + 0.3)
+    gw, gb = E.r(1 + U((Cin,), "co.gw", 0.1)), E.r(U((Cin,), "co.gb", 0.1))
+    w = E.r(U((Cout, Cin, 3, 3, 3), "co.w", 1 / math.sqrt(27 * Cin)))
+    b = E.r(U((Cout,), "co.b", 0.1))
+    xr = cl(x)
+    b8 = torch.zeros(8, dtype=F16, device=DEV)
+    b8[:Cout] = b.to(DEV).to(F16)
+    wf = V.cout4_weight_fragments(w.to(DEV))
+    aff = V.groupnorm_affine(xr, gw.to(DEV).to(F16), gb.to(DEV).to(F16)) if with_gn else None
+    got = V.conv_cout4(xr, aff, True, wf, b8, T, H, W, Cin, Cout)
+    assert got.shape == (T * H * W, 8) and float(got[:, Cout:].abs().max()) == 0.0
+    h = E.r(R.group_norm_silu(x, gw, gb)) if with_gn else x
+    ref = R.causal_conv3d(h, w, b, E)
+    torch.testing.assert_close(uncl(got[:, :Cout], T, H, W), ref, rtol=2e-3, atol=2e-3)
+    # the replaced form on the same fp16 activations
+    hr = V.groupnorm_apply(xr, aff, True) if with_gn else xr
+    cip = -(-Cin // 64) * 64
+    if cip != Cin:
+        hp = torch.zeros(hr.shape[0], cip, dtype=F16, device=DEV)
+        hp[:, :Cin] = hr
+        hr = hp
+    w8 = torch.zeros(8, Cin, 3, 3, 3)
+    w8[:Cout] = w
+    old = V.conv3d_causal(hr, taps(w8, cip), b8, T, H, W, cip, 8)
+    d = (got[:, :Cout].float() - old[:, :Cout].float()).abs()
+    ulp = torch.maximum(old[:, :Cout].float().abs(), torch.tensor(2.0 ** -14, device=DEV)) * 2.0 ** -10
+    assert float((d / ulp).max()) <= 2.0, float((d / ulp).max())
+    assert torch.equal(got, V.conv_cout4(xr, aff, True, wf, b8, T, H, W, Cin, Cout))     # fixed order: run-to-run identical
+
+
 # GroupNorm statistics taken in the conv epilogue (hv_conv3d_causal_f16 `gn_partial`) against the separate pass over the stored
 # tensor (hv_groupnorm_affine_f16): same affine.  Shapes chosen to go through every conv main loop that shares the epilogue:
 # 2-stage (Cin 64), pipelined 256x128 per-tap (W = 12) and shift-reuse (W = 16), pipelined 256x256 (Cin = Cout = 256); ragged
