@@ -197,6 +197,33 @@ def test_conv3d_production_shapes_sampled_voxels(name, cin, cout, T, Hh, W, up):
     torch.testing.assert_close(out[lin].float().cpu(), ref, rtol=2 ** -9, atol=4e-3)
 
 
+def test_decoder_tail_planes_production_shape_sampled_voxels():
+    """hv_conv3d_cout4_f16 (conv_norm_out + SiLU + conv_out as one streaming pass + a gather-sum) at the largest tile, 65 x 256 x 256 x
+    128 -> 3 (4.26 M voxels: 1.38 GB of fp32 planes, 64-bit plane offsets): sampled output voxels incl. every border against the
+    direct definition with the oracle's index semantics (fp64 sum over the 27 taps of the fp16-rounded normalised activations -
+    hv_groupnorm_apply_f16's output, checked on its own in test_gpu_vae.py); run-to-run identical."""
+    from hunyuanvideo_efficiency_amd import vae_ops as V
+    T, Hh, W, c, co = 65, 256, 256, 128, 3
+    x = (_u((T * Hh * W, c), "ct.x", 2.0, F16).float() + 0.3).to(F16)
+    gw, gb = (1 + _u((c,), "ct.gw", 0.1, F16).float()).to(F16), _u((c,), "ct.gb", 0.1, F16)
+    w5 = _u((co, c, 3, 3, 3), "ct.w", 1 / math.sqrt(27 * c), F16)
+    b8 = torch.zeros(8, dtype=F16, device=DEV)
+    b8[:co] = _u((co,), "ct.b", 0.1, F16)
+    aff = V.groupnorm_affine(x, gw, gb)
+    wf = V.cout4_weight_fragments(w5)
+    out = V.conv_cout4(x, aff, True, wf, b8, T, Hh, W, c, co)
+    again = V.conv_cout4(x, aff, True, wf, b8, T, Hh, W, c, co)
+    torch.cuda.synchronize()
+    assert torch.equal(out, again) and float(out[:, co:].abs().max()) == 0.0
+    del again
+    h = V.groupnorm_apply(x, aff, True)
+    vox = _sample_voxels(T, Hh, W, 1000, "ct.v")
+    wt = w5.permute(0, 2, 3, 4, 1).reshape(co, 27, c).contiguous()
+    ref = _conv_ref_voxels(h, T, Hh, W, wt, b8[:co], vox, T, Hh, W, False, False)
+    lin = ((vox[:, 0] * Hh + vox[:, 1]) * W + vox[:, 2]).to(DEV)
+    torch.testing.assert_close(out[lin, :co].float().cpu(), ref, rtol=2 ** -9, atol=2e-3)
+
+
 @pytest.mark.parametrize("name,c,sT,sH,sW,up_t,mode", [
     ("512ch_t_hw", 512, 17, 64, 64, True, "fast"),          # up_blocks.1 upsampler -> 33 x 128 x 128 (8 parity classes, 8 taps)
     ("256ch_hw", 256, 65, 128, 128, False, "fast"),         # up_blocks.2 upsampler -> 65 x 256 x 256 (4 classes, 12 taps): the largest
