@@ -3,7 +3,7 @@
 // the DATA in the operand registers.  The part is power-limited under dense MFMA work (1400 W cap): with zeros the stream runs near the
 // 2.5 PFLOP/s the clock allows, with random bf16 operands the clock drops.  That rate - not 2.5 PF - is the roof a bf16 attention or
 // GEMM kernel on real activations can approach on this part.
-// usage: mfma_power_roof [seconds per mode = 6] [waves per SIMD = 1] [16 | 32 = MFMA shape] [extra: 1 LDS reads, 2 softmax VALU, 3 both]
+// usage: mfma_power_roof [seconds per mode = 6] [waves per SIMD = 1] [16 | 32 = bf16 MFMA shape, 1632 = 16x16x32 f16] [extra: 1 LDS reads, 2 softmax VALU, 3 both]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -112,6 +112,30 @@ __global__ __launch_bounds__(256) void mfma_stream16(const uint4* __restrict__ a
     if (s == 12345.678f) sink[blockIdx.x * 256 + lane] = s;
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// ... and with v_mfma_f32_16x16x32_f16 (the VAE convs' instruction): the operand bits are random fp16 values
+__global__ __launch_bounds__(256) void mfma_stream16h(const uint4* __restrict__ a_src, const uint4* __restrict__ b_src, float* __restrict__ sink, int iters) {
+    const int lane = threadIdx.x;
+    f16x8 a[NFRAG], b[NFRAG];
+    for (int i = 0; i < NFRAG; ++i) {
+        a[i] = __builtin_bit_cast(f16x8, a_src[(size_t)(blockIdx.x * NFRAG + i) * 256 + lane]);
+        b[i] = __builtin_bit_cast(f16x8, b_src[(size_t)(blockIdx.x * NFRAG + i) * 256 + lane]);
+    }
+    f32x4 acc[16] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NFRAG; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(i + (j >> 2)) % NFRAG], b[(i + 2 * (j & 3)) % NFRAG], acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int j = 0; j < 16; ++j)
+        for (int r = 0; r < 4; ++r) s += acc[j][r];
+    if (s == 12345.678f) sink[blockIdx.x * 256 + lane] = s;
+}
+
+static uint16_t to_f16(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
 static uint16_t to_bf16(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -122,7 +146,8 @@ static uint16_t to_bf16(float f) {
 int main(int argc, char** argv) {
     double seconds = argc > 1 ? atof(argv[1]) : 6.0;
     int wps = argc > 2 ? atoi(argv[2]) : 1;
-    const bool s16 = argc > 3 && atoi(argv[3]) == 16;       // third argument 16: the 16x16x32 shape
+    const bool f16 = argc > 3 && atoi(argv[3]) == 1632;     // third argument 1632: 16x16x32 with fp16 operands
+    const bool s16 = argc > 3 && (atoi(argv[3]) == 16 || f16);       // third argument 16: the 16x16x32 shape
     const int extra = argc > 4 ? atoi(argv[4]) : 0;         // fourth argument: 1 = + LDS reads, 2 = + softmax VALU, 3 = both (32x32x16 only)
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -136,7 +161,7 @@ int main(int argc, char** argv) {
     std::normal_distribution<float> nd(0.f, 1.f);
     std::uniform_real_distribution<float> ud(0.f, 1.f);
     const char* modes[] = {"zeros x zeros", "N(0,1) x N(0,1)  (Q.K^T-like)", "U(0,1) x N(0,1)  (P.V-like)", "N(0,1) x zeros", "1.0 x N(0,1)"};
-    printf("%d CUs, %d wave(s) per SIMD, %s%s%s, %.0f s per mode\n", prop.multiProcessorCount, wps, s16 ? "v_mfma_f32_16x16x32_bf16" : "v_mfma_f32_32x32x16_bf16",
+    printf("%d CUs, %d wave(s) per SIMD, %s%s%s, %.0f s per mode\n", prop.multiProcessorCount, wps, f16 ? "v_mfma_f32_16x16x32_f16" : s16 ? "v_mfma_f32_16x16x32_bf16" : "v_mfma_f32_32x32x16_bf16",
            extra & 1 ? " + 0.5 KB LDS read per MFMA" : "", extra & 2 ? " + exp/add/pack per MFMA" : "", seconds);
     for (int m = 0; m < 5; ++m) {
         for (size_t i = 0; i < n16; ++i) {
@@ -145,14 +170,15 @@ int main(int argc, char** argv) {
             if (m == 2) { x = ud(rng); y = nd(rng); }
             if (m == 3) { x = nd(rng); }
             if (m == 4) { x = 1.f; y = nd(rng); }
-            ha[i] = to_bf16(x); hb[i] = to_bf16(y);
+            ha[i] = f16 ? to_f16(x) : to_bf16(x); hb[i] = f16 ? to_f16(y) : to_bf16(y);
         }
         hipMemcpy(da, ha.data(), n16 * 2, hipMemcpyHostToDevice);
         hipMemcpy(db, hb.data(), n16 * 2, hipMemcpyHostToDevice);
         const int iters = s16 ? 20000 : 40000;        // 32 (128) MFMAs per iteration per wave
         const double flop_per_launch = (double)blocks * 4 * iters * (s16 ? 128 * (2.0 * 16 * 16 * 32) : 32 * (2.0 * 32 * 32 * 16));
         auto launch = [&](int n) {
-            if (s16) mfma_stream16<<<blocks, 256>>>(da, db, sink, n);
+            if (f16) mfma_stream16h<<<blocks, 256>>>(da, db, sink, n);
+            else if (s16) mfma_stream16<<<blocks, 256>>>(da, db, sink, n);
             else if (extra == 1) mfma_stream_fill<1><<<blocks, 256>>>(da, db, sink, n);
             else if (extra == 2) mfma_stream_fill<2><<<blocks, 256>>>(da, db, sink, n);
             else if (extra == 3) mfma_stream_fill<3><<<blocks, 256>>>(da, db, sink, n);
