@@ -31,6 +31,8 @@
 // Iteration t (64 MFMA gaps, one scheduling fence per gap; consumes S'(t), produces S'(t+1)):
 //   gaps  0-31  S'(t+1) chains, K fragment f = gap/2 for both query blocks | 40 of the 64 exp2 of P(t) (5 per 4 gaps), packs, row sums
 //   gaps 32-63  O += V(t).P(t), V fragment per two gaps                    | the other 24 exp2 (gaps 32-54), row max of S'(t+1) (online mode only)
+//   inside a gap of the generated statement: MFMA, then the memory instructions (fragment reads, the DMA piece), then the VALU fillers
+//   (packs, row sums, exponentials, row max) - memory first measured +2.9 % over VALU first (profiles/r03/attn_filler_order.txt)
 //   fragment f is read from LDS four fragments (eight gaps, > 256 cycles) ahead of its first MFMA, which waits with a counted
 //   lgkmcnt (one wait per pair of fragments); barrier at gap 56 (vmcnt only: no buffer read in this iteration is a DMA target before
 //   the next barrier), then the first four K fragments of the next tile.
