@@ -3,7 +3,7 @@
 // the DATA in the operand registers.  The part is power-limited under dense MFMA work (1400 W cap): with zeros the stream runs near the
 // 2.5 PFLOP/s the clock allows, with random bf16 operands the clock drops.  That rate - not 2.5 PF - is the roof a bf16 attention or
 // GEMM kernel on real activations can approach on this part.
-// usage: mfma_power_roof [seconds per mode = 6] [waves per SIMD = 1] [16 | 32 = bf16 MFMA shape, 1632 = 16x16x32 f16] [extra: 1 LDS reads, 2 softmax VALU, 3 both]
+// usage: mfma_power_roof [seconds per mode = 6] [waves per SIMD = 1] [16 | 32 = bf16 MFMA shape, 1632 = 16x16x32 f16] [extra: 1 LDS reads, 2 softmax VALU, 3 both, 4 / 8 / 16 = one exp / add / pack per MFMA]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +80,15 @@ __global__ __launch_bounds__(256) void mfma_stream_fill(const uint4* __restrict_
                         unsigned pk;
                         asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(e), "v"(l));
                     }
+                }
+                if (EXTRA & 4) {        // the pieces of the softmax VALU on their own: 4 = one v_exp_f32 per MFMA, 8 = one v_add_f32, 16 = one v_cvt_pk per MFMA
+                    float e;
+                    asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(x[j]));
+                }
+                if (EXTRA & 8) asm volatile("v_add_f32 %0, %0, %1" : "+v"(l) : "v"(x[j]));
+                if (EXTRA & 16) {
+                    unsigned pk;
+                    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x[j]), "v"(x[(j + 1) & 3]));
                 }
             }
         if (EXTRA & 1) asm volatile("s_waitcnt lgkmcnt(0)");
@@ -162,7 +171,7 @@ int main(int argc, char** argv) {
     std::uniform_real_distribution<float> ud(0.f, 1.f);
     const char* modes[] = {"zeros x zeros", "N(0,1) x N(0,1)  (Q.K^T-like)", "U(0,1) x N(0,1)  (P.V-like)", "N(0,1) x zeros", "1.0 x N(0,1)"};
     printf("%d CUs, %d wave(s) per SIMD, %s%s%s, %.0f s per mode\n", prop.multiProcessorCount, wps, f16 ? "v_mfma_f32_16x16x32_f16" : s16 ? "v_mfma_f32_16x16x32_bf16" : "v_mfma_f32_32x32x16_bf16",
-           extra & 1 ? " + 0.5 KB LDS read per MFMA" : "", extra & 2 ? " + exp/add/pack per MFMA" : "", seconds);
+           extra & 1 ? " + 0.5 KB LDS read per MFMA" : "", extra & 2 ? " + exp/add/pack per MFMA" : extra == 4 ? " + v_exp_f32 per MFMA" : extra == 8 ? " + v_add_f32 per MFMA" : extra == 16 ? " + v_cvt_pk_bf16_f32 per MFMA" : "", seconds);
     for (int m = 0; m < 5; ++m) {
         for (size_t i = 0; i < n16; ++i) {
             float x = 0.f, y = 0.f;
@@ -182,6 +191,9 @@ int main(int argc, char** argv) {
             else if (extra == 1) mfma_stream_fill<1><<<blocks, 256>>>(da, db, sink, n);
             else if (extra == 2) mfma_stream_fill<2><<<blocks, 256>>>(da, db, sink, n);
             else if (extra == 3) mfma_stream_fill<3><<<blocks, 256>>>(da, db, sink, n);
+            else if (extra == 4) mfma_stream_fill<4><<<blocks, 256>>>(da, db, sink, n);
+            else if (extra == 8) mfma_stream_fill<8><<<blocks, 256>>>(da, db, sink, n);
+            else if (extra == 16) mfma_stream_fill<16><<<blocks, 256>>>(da, db, sink, n);
             else mfma_stream<<<blocks, 256>>>(da, db, sink, n);
         };
         launch(1000);
